@@ -1,0 +1,160 @@
+/*
+ * sdr_amd.h -- C ABI of the MI355X (gfx950) batched SDR set-algebra engine.
+ *
+ * An SDR (sparse distributed representation) is an ascending, duplicate-free sequence of
+ * (int id, payload) elements.  The reference library (jagprog5/SDR, header-only C++17)
+ * evaluates one pair of SDRs per call on one CPU thread; it has no FFI of its own, so each
+ * entry point below cites the reference member function(s) whose per-pair result it
+ * reproduces, bit for bit, for every pair of a batch.  Paths are relative to the
+ * reference's include/SparseDistributedRepresentation/.
+ *
+ * Conventions
+ *  - A "batch" is a device-resident CSR pack of many SDRs of one element type:
+ *    uint32 row_offsets[n_rows+1], int32 ids[nnz], optional float data[nnz].
+ *  - Binary operations take two batches A and B and evaluate every pair:
+ *        result(i, j) = A_i.op(B_j)            (A_i is `this`, B_j is `arg`)
+ *    or, with SDRB_FLAG_SWAP, B_j.op(A_i).  Results are indexed [i][j], j fastest.
+ *    B is the long, streamed side (the database); A is the short side (the queries).
+ *  - All functions return SDRB_OK (0) or a negative error code and never throw;
+ *    sdrb_last_error() gives a thread-local message for the last failure.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is
+ *    enqueued asynchronously unless a function says it synchronises.
+ *  - Device pointers passed in (out buffers, offsets) must live on the batch's device.
+ *  - Handles are thread-compatible: use one handle from one thread at a time.
+ */
+#ifndef SDR_AMD_H
+#define SDR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRB_OK 0
+#define SDRB_ERR_INVALID_ARG (-1)
+#define SDRB_ERR_NOT_ASCENDING (-2) /* a row's ids are not strictly ascending */
+#define SDRB_ERR_ID_RANGE (-3)      /* an id lies outside [0, width) of a batch with a declared width */
+#define SDRB_ERR_HIP (-4)           /* a HIP runtime call failed; see sdrb_last_error() */
+#define SDRB_ERR_UNSUPPORTED (-5)
+#define SDRB_ERR_OVERFLOW (-6)      /* more than 2^32-1 elements in one batch or one result */
+#define SDRB_ERR_PAYLOAD_RANGE (-7) /* a UnitData payload outside [0,1] (UnitData.hpp:15-17) */
+
+/* set operations */
+#define SDRB_OP_AND 0
+#define SDRB_OP_OR 1
+#define SDRB_OP_XOR 2
+#define SDRB_OP_RM 3
+
+/* payload kinds of a batch's elements */
+#define SDRB_DATA_EMPTY 0 /* DataTypes/EmptyData.hpp:18-92: zero-size payload */
+#define SDRB_DATA_UNIT 1  /* DataTypes/UnitData.hpp:11-140: float in [0,1] */
+
+/* flags of the binary operations */
+#define SDRB_FLAG_SWAP 1u           /* result(i,j) = B_j.op(A_i) instead of A_i.op(B_j) */
+#define SDRB_FLAG_FORCE_MERGE 2u    /* size ops: always use the per-pair merge kernel */
+#define SDRB_FLAG_FORCE_BITSLICE 4u /* size ops: fail with UNSUPPORTED unless the bit-sliced kernel applies */
+
+typedef struct sdrb_batch sdrb_batch;
+
+/* Message of the calling thread's most recent failure ("" if none). */
+const char* sdrb_last_error(void);
+
+/* Number of visible HIP devices. */
+int sdrb_device_count(int* count);
+
+/*
+ * Creates an empty batch on `device`.
+ * width > 0 declares that every id lies in [0, width) (checked at upload); width == 0
+ * means arbitrary signed ids (SDRElem.hpp:15,73-75).  The table-driven kernels need a
+ * declared width; without one only the merge kernels are used.
+ * Replaces: the container side of SDR<SDRElem<int,Data>, Container> (SDR.hpp:26-27,573);
+ * the struct-of-arrays layout mirrors IDContiguousContainer.hpp:246-250.
+ */
+int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out);
+
+/*
+ * Packs n_rows SDRs given as host CSR (row_offsets has n_rows+1 entries, ids/data have
+ * row_offsets[n_rows] entries; data is NULL for SDRB_DATA_EMPTY) into HBM, replacing any
+ * previous content.  Rows must be strictly ascending (SDR.hpp:679,1621 assert the same),
+ * ids must respect the declared width, UnitData payloads must lie in [0,1].  Payloads
+ * below the relevance threshold are kept as they are, exactly like the reference's
+ * iterator constructor and push_back (SDR.hpp:83,612-637,1614-1628).
+ * Synchronises: the host buffers may be reused on return.
+ */
+int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
+                          const int32_t* ids, const float* data, void* stream);
+
+/* Shape of a batch; any out pointer may be NULL. */
+int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint64_t* nnz,
+                    int32_t* width, int* data_kind, uint32_t* max_row_len);
+
+/* Device pointers of the packed CSR (read-only views, valid until the next upload/destroy). */
+int sdrb_batch_device_ptrs(const sdrb_batch* batch, const uint32_t** row_offsets,
+                           const int32_t** ids, const float** data);
+
+int sdrb_batch_destroy(sdrb_batch* batch);
+
+/*
+ * Size operations for every pair: out[i*ld_out + j] (uint32, device memory, ld_out >= B rows)
+ *   SDRB_OP_AND -> ands  (SDR.hpp:1083-1095)     SDRB_OP_OR -> ors  (SDR.hpp:1294-1304)
+ *   SDRB_OP_XOR -> xors  (SDR.hpp:1424-1434)     SDRB_OP_RM -> rms  (SDR.hpp:1568-1577)
+ * including the payload predicates of EmptyData.hpp:50-51,70-71,79-80 and
+ * UnitData.hpp:48-51,94-97,117-120 (single IEEE binary32 operations, threshold >= 0.1).
+ * The reference returns size_t; counts here are uint32 (a row has < 2^32 elements).
+ * Kernel choice: when the result depends on ids only (`this` side is EmptyData, or the
+ * op is ors) and B has a declared width that fits the LDS table, a bit-sliced
+ * table kernel is used; otherwise a per-pair merge kernel (the visitor merge
+ * andv, SDR.hpp:958-997, restated per lane).
+ */
+int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                 uint32_t* out, uint64_t ld_out, void* stream);
+
+/*
+ * Element operations for every pair, as a two-call CSR protocol:
+ *   SDRB_OP_AND -> ande (SDR.hpp:999-1025)       SDRB_OP_OR -> ore  (SDR.hpp:1183-1222)
+ *   SDRB_OP_XOR -> xore (SDR.hpp:1307-1349)      SDRB_OP_RM -> rme  (SDR.hpp:1515-1566)
+ * The in-place forms andi/ori/xori/rmi (SDR.hpp:1027-1081,1239-1292,1366-1513) produce the
+ * same elements; a caller replaces row i of its own storage with result (i, j).
+ * Result elements have the element type of the `this` side (the reference's default
+ * ret_t): ids always, payloads only when `this` is UnitData.
+ *
+ * 1) sdrb_elem_op_count fills out_offsets[na*nb + 1] (uint32, device) with the exclusive
+ *    prefix sum of the result lengths in [i][j] order and returns the total in
+ *    *total (host).  Synchronises the stream.
+ * 2) the caller allocates out_ids[total] (and out_data[total] when `this` is UnitData);
+ * 3) sdrb_elem_op_fill writes result (i, j) at out_offsets[i*nb + j], ascending by id.
+ */
+int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                       uint32_t* out_offsets, uint64_t* total, void* stream);
+int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                      const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
+                      void* stream);
+
+/*
+ * Device-memory helpers for callers that do not link a HIP runtime themselves (the C++
+ * SDRBatch front end, ctypes/cgo/JNI bindings).  sdrb_memcpy_* synchronise.
+ */
+int sdrb_malloc(int device, size_t bytes, void** ptr);
+int sdrb_free(int device, void* ptr);
+int sdrb_memcpy_h2d(int device, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int sdrb_memcpy_d2h(int device, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int sdrb_stream_sync(int device, void* stream);
+
+/*
+ * Deterministic synthetic rows for the bench/verify harness (no reference counterpart;
+ * the reference's fuzzer draws from std::mt19937, src/fuzz.cpp:181-219).
+ * Row r (global index first_row + k) is the sorted first `active` entries of a partial
+ * Fisher-Yates shuffle of 0..width-1 driven by splitmix64 seeded with
+ * seed ^ (r * 0x9E3779B97F4A7C15); payloads, when `data` is non-NULL, are
+ * (x >> 40) * 2^-24 drawn after the ids, in id order, and are not filtered for relevance.
+ * Host-only: writes row_offsets[n_rows+1], ids[n_rows*active], data[n_rows*active].
+ */
+int sdrb_synth_csr(uint64_t seed, uint64_t first_row, uint64_t n_rows, int32_t width,
+                   int32_t active, uint64_t* row_offsets, int32_t* ids, float* data);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_AMD_H */

@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE -- NOT PART OF THE SHIPPED ENGINE.
+
+ctypes access to the CPU oracle (``libsdr_oracle.so``, the plain-C restatement in
+``sdr_oracle.c``) and, when it has been built, to the real reference behind
+``ref_driver.cpp`` (``_ref/libsdr_ref.so``).  Only tests, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libsdr_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libsdr_ref.so")
+REF_DBG_SO = os.path.join(_HERE, "_ref", "libsdr_ref_dbg.so")
+REF_FUZZ = os.path.join(_HERE, "_ref", "fuzz_sdr")
+
+EMPTY, UNIT = 0, 1
+AND, OR, XOR, RM = 0, 1, 2, 3
+OP_NAMES = {AND: "and", OR: "or", XOR: "xor", RM: "rm"}
+
+_vp = C.c_void_p
+_BATCH_ARGS = [_vp, _vp, _vp, C.c_int, C.c_uint64] * 2  # (off, ids, data, kind, n) x2
+
+
+def build(ref: bool = True) -> None:
+    """Compiles the oracle (and the reference driver where /root/reference exists)."""
+    subprocess.run(["make", "-C", _HERE, "-s"] + ([] if ref else ["libsdr_oracle.so"]), check=True)
+
+
+class Batch:
+    """Host CSR pack: offsets uint64[n+1], ids int32, data float32 or None."""
+
+    def __init__(self, offsets, ids, data=None):
+        self.off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self.data = None if data is None else np.ascontiguousarray(data, dtype=np.float32)
+        self.kind = EMPTY if data is None else UNIT
+        self.n = self.off.size - 1
+        assert int(self.off[-1]) == self.ids.size
+        assert self.data is None or self.data.size == self.ids.size
+
+    @classmethod
+    def from_rows(cls, rows, with_data=False):
+        off, ids, data = [0], [], []
+        for row in rows:
+            if with_data:
+                r_ids, r_data = row
+                data.extend(r_data)
+            else:
+                r_ids = row
+            ids.extend(r_ids)
+            off.append(len(ids))
+        return cls(off, ids, data if with_data else None)
+
+    def args(self):
+        return [self.off.ctypes.data_as(_vp), self.ids.ctypes.data_as(_vp),
+                self.data.ctypes.data_as(_vp) if self.data is not None else None, self.kind, self.n]
+
+    def row(self, r):
+        lo, hi = int(self.off[r]), int(self.off[r + 1])
+        return self.ids[lo:hi], (self.data[lo:hi] if self.data is not None else None)
+
+    def nbytes(self):
+        return self.off.nbytes + self.ids.nbytes + (self.data.nbytes if self.data is not None else 0)
+
+
+class _Impl:
+    """One implementation (restatement or real reference) of the batch entry points."""
+
+    def __init__(self, path: str, prefix: str, has_inplace_flag: bool):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.is_reference = has_inplace_flag
+        f = getattr(self.lib, prefix + "batch_size_op")
+        f.restype, f.argtypes = None, [C.c_int] + _BATCH_ARGS + [_vp]
+        f = getattr(self.lib, prefix + "batch_elem_op")
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_int] + ([C.c_int] if has_inplace_flag else []) + _BATCH_ARGS + [_vp, _vp, _vp]
+        f = getattr(self.lib, prefix + "time_size_op")
+        f.restype = C.c_double
+        f.argtypes = [C.c_int] + _BATCH_ARGS + [C.c_int] + ([C.c_int] if has_inplace_flag else []) + [_vp]
+
+    def size_op(self, op: int, t: Batch, a: Batch) -> np.ndarray:
+        out = np.zeros((t.n, a.n), dtype=np.uint32)
+        getattr(self.lib, self.prefix + "batch_size_op")(op, *t.args(), *a.args(), out.ctypes.data_as(_vp))
+        return out
+
+    def elem_op(self, op: int, t: Batch, a: Batch, inplace: bool = False):
+        """Returns (offsets uint64[t.n*a.n+1], ids, data-or-None) of this_i.op(arg_j)."""
+        fn = getattr(self.lib, self.prefix + "batch_elem_op")
+        head = [op] + ([1 if inplace else 0] if self.is_reference else [])
+        if inplace and not self.is_reference:
+            raise ValueError("the restatement exposes in-place ops through inplace_op()")
+        off = np.zeros(t.n * a.n + 1, dtype=np.uint64)
+        total = fn(*head, *t.args(), *a.args(), off.ctypes.data_as(_vp), None, None)
+        ids = np.zeros(total, dtype=np.int32)
+        data = np.zeros(total, dtype=np.float32) if t.kind == UNIT else None
+        fn(*head, *t.args(), *a.args(), off.ctypes.data_as(_vp), ids.ctypes.data_as(_vp),
+           data.ctypes.data_as(_vp) if data is not None else None)
+        return off, ids, data
+
+    def time_size_op(self, op: int, t: Batch, a: Batch, repeats: int = 3, threads: int = 1):
+        """Best-of-``repeats`` seconds for one pass over all pairs, and the result checksum."""
+        chk = C.c_uint64()
+        fn = getattr(self.lib, self.prefix + "time_size_op")
+        tail = [repeats] + ([threads] if self.is_reference else []) + [C.byref(chk)]
+        if threads != 1 and not self.is_reference:
+            raise ValueError("the C restatement is timed on one thread")
+        sec = fn(op, *t.args(), *a.args(), *tail)
+        return sec, int(chk.value)
+
+
+_port = None
+_refs = {}
+
+
+def port() -> _Impl:
+    """The plain-C restatement (always available once built)."""
+    global _port
+    if _port is None:
+        if not os.path.exists(ORACLE_SO):
+            build(ref=False)
+        _port = _Impl(ORACLE_SO, "osdr_", False)
+        _port.lib.osdr_inplace_op.restype = C.c_size_t
+        _port.lib.osdr_inplace_op.argtypes = [C.c_int, _vp, _vp, C.c_size_t, C.c_int, _vp]
+    return _port
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def reference(debug: bool = False) -> _Impl:
+    """The real reference (oracle/_ref); ``debug`` keeps its asserts on."""
+    path = REF_DBG_SO if debug else REF_SO
+    if path not in _refs:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built (needs /root/reference; run make -C oracle ref)")
+        impl = _Impl(path, "rsdr_", True)
+        impl.lib.rsdr_inplace_self.restype = C.c_uint64
+        impl.lib.rsdr_inplace_self.argtypes = [C.c_int, _vp, _vp, C.c_uint64, C.c_int]
+        _refs[path] = impl
+    return _refs[path]
+
+
+class _View(C.Structure):
+    _fields_ = [("ids", _vp), ("data", _vp), ("n", C.c_size_t), ("kind", C.c_int)]
+
+
+def port_inplace(op: int, t_ids, t_data, a_ids, a_data, alias: bool = False):
+    """this.opi(arg) on the restatement; ``alias`` passes this's own arrays as the argument."""
+    p = port()
+    t_kind = EMPTY if t_data is None else UNIT
+    n_t = len(t_ids)
+    n_a = n_t if alias else len(a_ids)
+    ids = np.zeros(n_t + n_a + 1, dtype=np.int32)
+    ids[:n_t] = t_ids
+    data = np.zeros(n_t + n_a + 1, dtype=np.float32)
+    if t_data is not None:
+        data[:n_t] = t_data
+    if alias:
+        view = _View(ids.ctypes.data, data.ctypes.data if t_data is not None else None, n_t, t_kind)
+    else:
+        a_ids = np.ascontiguousarray(a_ids, dtype=np.int32)
+        a_data_arr = None if a_data is None else np.ascontiguousarray(a_data, dtype=np.float32)
+        view = _View(a_ids.ctypes.data, a_data_arr.ctypes.data if a_data_arr is not None else None,
+                     n_a, EMPTY if a_data is None else UNIT)
+    n = p.lib.osdr_inplace_op(op, ids.ctypes.data_as(_vp),
+                              data.ctypes.data_as(_vp) if t_data is not None else None, n_t, t_kind,
+                              C.byref(view))
+    return ids[:n].copy(), (data[:n].copy() if t_data is not None else None)

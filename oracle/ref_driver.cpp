@@ -1,0 +1,231 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PART OF THE SHIPPED ENGINE.
+ *
+ * extern "C" driver over the REAL reference headers.  It is compiled only where
+ * /root/reference exists (see oracle/Makefile); the headers are included from where
+ * they lie and nothing of them is copied here.  The resulting oracle/_ref/libsdr_ref.so
+ * is what pins the C restatement in sdr_oracle.c, generates the golden fixtures, and
+ * serves as the "reference" CPU baseline of the benchmark.
+ *
+ * Same batch signatures as sdr_oracle.h with an rsdr_ prefix.  Rows become
+ * SDR<SDRElem<int,EmptyData>> / SDR<SDRElem<int,UnitData>> on std::vector, the
+ * reference's default container (SDR.hpp:26), built with push_back (SDR.hpp:1614-1628:
+ * no relevance filtering, ascending order asserted).
+ */
+#include "SparseDistributedRepresentation/SDR.hpp"
+#include "SparseDistributedRepresentation/DataTypes/UnitData.hpp"
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace sparse_distributed_representation;
+
+namespace {
+
+using EmptyElem = SDRElem<int, EmptyData>;
+using UnitElem = SDRElem<int, UnitData>;
+using EmptySDR = SDR<EmptyElem>;
+using UnitSDR = SDR<UnitElem>;
+
+enum { K_EMPTY = 0, K_UNIT = 1 };
+enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_RM = 3 };
+
+template <typename S>
+std::vector<S> build(const uint64_t* off, const int32_t* ids, const float* data, uint64_t n) {
+    std::vector<S> rows(n);
+    for (uint64_t r = 0; r < n; ++r) {
+        for (uint64_t k = off[r]; k < off[r + 1]; ++k) {
+            if constexpr (std::is_same_v<S, UnitSDR>) {
+                rows[r].push_back(UnitElem(ids[k], UnitData(data[k])));
+            } else {
+                rows[r].push_back(EmptyElem(ids[k]));
+            }
+        }
+    }
+    return rows;
+}
+
+template <typename A, typename B>
+size_t size_op(int op, const A& a, const B& b) {
+    switch (op) {
+    case OP_AND: return a.ands(b);
+    case OP_OR: return a.ors(b);
+    case OP_XOR: return a.xors(b);
+    default: return a.rms(b);
+    }
+}
+
+template <typename A, typename B>
+A elem_op(int op, const A& a, const B& b) {
+    switch (op) {
+    case OP_AND: return a.ande(b);
+    case OP_OR: return a.ore(b);
+    case OP_XOR: return a.xore(b);
+    default: return a.rme(b);
+    }
+}
+
+template <typename A, typename B>
+void inplace_op(int op, A& a, const B& b) {
+    switch (op) {
+    case OP_AND: a.andi(b); break;
+    case OP_OR: a.ori(b); break;
+    case OP_XOR: a.xori(b); break;
+    default: a.rmi(b); break;
+    }
+}
+
+template <typename S>
+float payload(const typename S::value_type& e) {
+    if constexpr (std::is_same_v<S, UnitSDR>) return e.data().value();
+    else return 0.0f;
+}
+
+template <typename A, typename B>
+void batch_size(int op, const std::vector<A>& t, const std::vector<B>& a, uint32_t* out) {
+    for (size_t i = 0; i < t.size(); ++i)
+        for (size_t j = 0; j < a.size(); ++j)
+            out[i * a.size() + j] = (uint32_t)size_op(op, t[i], a[j]);
+}
+
+template <typename A, typename B>
+uint64_t batch_elem(int op, bool inplace, const std::vector<A>& t, const std::vector<B>& a,
+                    uint64_t* out_off, int32_t* out_ids, float* out_data) {
+    uint64_t total = 0;
+    for (size_t i = 0; i < t.size(); ++i)
+        for (size_t j = 0; j < a.size(); ++j) {
+            out_off[i * a.size() + j] = total;
+            A r;
+            if (inplace) {
+                r = t[i];
+                inplace_op(op, r, a[j]);
+            } else {
+                r = elem_op(op, t[i], a[j]);
+            }
+            if (out_ids) {
+                uint64_t k = total;
+                for (auto it = r.cbegin(); it != r.cend(); ++it, ++k) {
+                    out_ids[k] = it->id();
+                    if (out_data) out_data[k] = payload<A>(*it);
+                }
+            }
+            total += r.size();
+        }
+    out_off[t.size() * a.size()] = total;
+    return total;
+}
+
+template <typename A, typename B>
+double time_size(int op, const std::vector<A>& t, const std::vector<B>& a, int repeats,
+                 int threads, uint64_t* checksum) {
+    double best = 1e300;
+    uint64_t sum_out = 0;
+    if (threads < 1) threads = 1;
+    for (int r = 0; r < repeats; ++r) {
+        std::vector<uint64_t> sums(threads, 0);
+        auto work = [&](int w) {
+            // arg rows statically partitioned over the workers
+            size_t lo = a.size() * w / threads, hi = a.size() * (w + 1) / threads;
+            uint64_t s = 0;
+            for (size_t i = 0; i < t.size(); ++i)
+                for (size_t j = lo; j < hi; ++j) s += size_op(op, t[i], a[j]);
+            sums[w] = s;
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        if (threads == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int w = 0; w < threads; ++w) pool.emplace_back(work, w);
+            for (auto& th : pool) th.join();
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        double s = std::chrono::duration<double>(t1 - t0).count();
+        if (s < best) best = s;
+        sum_out = 0;
+        for (auto v : sums) sum_out += v;
+    }
+    if (checksum) *checksum = sum_out;
+    return best;
+}
+
+}  // namespace
+
+#define DISPATCH(tk, ak, CALL)                                                        \
+    do {                                                                              \
+        if ((tk) == K_EMPTY && (ak) == K_EMPTY) { CALL(EmptySDR, EmptySDR); }         \
+        else if ((tk) == K_EMPTY && (ak) == K_UNIT) { CALL(EmptySDR, UnitSDR); }      \
+        else if ((tk) == K_UNIT && (ak) == K_EMPTY) { CALL(UnitSDR, EmptySDR); }      \
+        else { CALL(UnitSDR, UnitSDR); }                                              \
+    } while (0)
+
+extern "C" {
+
+void rsdr_batch_size_op(int op,
+                        const uint64_t* t_off, const int32_t* t_ids, const float* t_data,
+                        int t_kind, uint64_t t_n,
+                        const uint64_t* a_off, const int32_t* a_ids, const float* a_data,
+                        int a_kind, uint64_t a_n, uint32_t* out) {
+#define CALL(A, B)                                          \
+    auto t = build<A>(t_off, t_ids, t_data, t_n);           \
+    auto a = build<B>(a_off, a_ids, a_data, a_n);           \
+    batch_size(op, t, a, out)
+    DISPATCH(t_kind, a_kind, CALL);
+#undef CALL
+}
+
+uint64_t rsdr_batch_elem_op(int op, int inplace,
+                            const uint64_t* t_off, const int32_t* t_ids, const float* t_data,
+                            int t_kind, uint64_t t_n,
+                            const uint64_t* a_off, const int32_t* a_ids, const float* a_data,
+                            int a_kind, uint64_t a_n,
+                            uint64_t* out_off, int32_t* out_ids, float* out_data) {
+    uint64_t total = 0;
+#define CALL(A, B)                                          \
+    auto t = build<A>(t_off, t_ids, t_data, t_n);           \
+    auto a = build<B>(a_off, a_ids, a_data, a_n);           \
+    total = batch_elem(op, inplace != 0, t, a, out_off, out_ids, t_kind == K_UNIT ? out_data : nullptr)
+    DISPATCH(t_kind, a_kind, CALL);
+#undef CALL
+    return total;
+}
+
+/* a.op(a) with the SAME object on both sides (src/test.cpp:241-272). Returns new length. */
+uint64_t rsdr_inplace_self(int op, int32_t* ids, float* data, uint64_t n, int kind) {
+    uint64_t off[2] = {0, n};
+    uint64_t len = 0;
+    if (kind == K_UNIT) {
+        auto v = build<UnitSDR>(off, ids, data, 1);
+        inplace_op(op, v[0], v[0]);
+        for (auto it = v[0].cbegin(); it != v[0].cend(); ++it, ++len) {
+            ids[len] = it->id();
+            data[len] = it->data().value();
+        }
+    } else {
+        auto v = build<EmptySDR>(off, ids, data, 1);
+        inplace_op(op, v[0], v[0]);
+        for (auto it = v[0].cbegin(); it != v[0].cend(); ++it, ++len) ids[len] = it->id();
+    }
+    return len;
+}
+
+double rsdr_time_size_op(int op,
+                         const uint64_t* t_off, const int32_t* t_ids, const float* t_data,
+                         int t_kind, uint64_t t_n,
+                         const uint64_t* a_off, const int32_t* a_ids, const float* a_data,
+                         int a_kind, uint64_t a_n,
+                         int repeats, int threads, uint64_t* checksum) {
+    double best = 0;
+#define CALL(A, B)                                          \
+    auto t = build<A>(t_off, t_ids, t_data, t_n);           \
+    auto a = build<B>(a_off, a_ids, a_data, a_n);           \
+    best = time_size(op, t, a, repeats, threads, checksum)
+    DISPATCH(t_kind, a_kind, CALL);
+#undef CALL
+    return best;
+}
+
+}  // extern "C"

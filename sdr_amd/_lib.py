@@ -1,0 +1,83 @@
+"""ctypes binding of ``libsdr_amd.so`` (declared in ``include/sdr_amd.h``).
+
+There is no CPU fallback: if the shared library is missing the import fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdr_amd.so")
+
+OK = 0
+OP_AND, OP_OR, OP_XOR, OP_RM = 0, 1, 2, 3
+DATA_EMPTY, DATA_UNIT = 0, 1
+FLAG_SWAP, FLAG_FORCE_MERGE, FLAG_FORCE_BITSLICE = 1, 2, 4
+
+ERROR_NAMES = {
+    -1: "SDRB_ERR_INVALID_ARG",
+    -2: "SDRB_ERR_NOT_ASCENDING",
+    -3: "SDRB_ERR_ID_RANGE",
+    -4: "SDRB_ERR_HIP",
+    -5: "SDRB_ERR_UNSUPPORTED",
+    -6: "SDRB_ERR_OVERFLOW",
+    -7: "SDRB_ERR_PAYLOAD_RANGE",
+}
+
+
+class SdrbError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+# name -> (restype, argtypes); every symbol include/sdr_amd.h declares
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+PROTOTYPES = {
+    "sdrb_last_error": (C.c_char_p, []),
+    "sdrb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sdrb_batch_create": (C.c_int, [C.c_int, C.c_int32, C.c_int, C.POINTER(_vp)]),
+    "sdrb_batch_upload_csr": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "sdrb_batch_info": (C.c_int, [_vp, C.POINTER(C.c_int), _u64p, _u64p, _i32p, C.POINTER(C.c_int), _u32p]),
+    "sdrb_batch_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sdrb_batch_destroy": (C.c_int, [_vp]),
+    "sdrb_size_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
+    "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
+    "sdrb_elem_op_fill": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),
+    "sdrb_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),
+    "sdrb_free": (C.c_int, [C.c_int, _vp]),
+    "sdrb_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "sdrb_memcpy_d2h": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "sdrb_stream_sync": (C.c_int, [C.c_int, _vp]),
+    "sdrb_synth_csr": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the engine; raises if it has not been built (``make -C sdr_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C sdr_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise SdrbError(rc, load().sdrb_last_error().decode("utf-8", "replace"))

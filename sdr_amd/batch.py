@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's set-algebra interface, batched.
+
+The reference evaluates ``a.ands(b)``, ``a.ande(b)`` ... for one pair of SDRs
+(``SDR.hpp:151-318``).  :class:`SDRBatch` packs many SDRs of one element type into a
+device-resident CSR batch and offers the same operation names over every pair
+``(self[i], other[j])``; ``self[i]`` plays ``this`` and ``other[j]`` plays ``arg`` unless
+``swap=True``.  All computation happens in ``libsdr_amd.so`` through the C ABI of
+``include/sdr_amd.h``; torch is used only to allocate result buffers and to name streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_SWAP,
+                   OP_AND, OP_OR, OP_RM, OP_XOR, check)
+
+_KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT}
+
+
+def _torch():
+    import torch  # plumbing only: device buffers and streams
+    return torch
+
+
+def _stream_handle(device: int, stream) -> int:
+    if stream is None:
+        torch = _torch()
+        return int(torch.cuda.current_stream(device).cuda_stream)
+    if hasattr(stream, "cuda_stream"):
+        return int(stream.cuda_stream)
+    return int(stream)
+
+
+def rows_to_csr(rows: Iterable, with_data: bool):
+    """``rows``: iterable of id sequences, or of ``(ids, data)`` pairs when ``with_data``."""
+    offsets = [0]
+    ids, data = [], []
+    for row in rows:
+        if with_data:
+            r_ids, r_data = row
+            if len(r_ids) != len(r_data):
+                raise ValueError("ids and data of a row differ in length")
+            data.extend(float(x) for x in r_data)
+        else:
+            r_ids = row
+        ids.extend(int(x) for x in r_ids)
+        offsets.append(len(ids))
+    return (np.asarray(offsets, dtype=np.uint64), np.asarray(ids, dtype=np.int32),
+            np.asarray(data, dtype=np.float32) if with_data else None)
+
+
+@dataclass
+class ElemResult:
+    """CSR result of an element op over all pairs: pair (i, j) owns
+    ``ids[offsets[i*nb+j] : offsets[i*nb+j+1]]`` (and ``data`` likewise, UnitData only)."""
+    na: int
+    nb: int
+    offsets: "object"            # torch.int32 [na*nb + 1] (values are uint32)
+    ids: "object"                # torch.int32 [total]
+    data: Optional["object"]     # torch.float32 [total] or None
+    total: int
+
+    def to_host(self):
+        off = self.offsets.cpu().numpy().view(np.uint32).astype(np.uint64)
+        ids = self.ids.cpu().numpy()
+        data = self.data.cpu().numpy() if self.data is not None else None
+        return off, ids, data
+
+
+class SDRBatch:
+    """A device-resident CSR pack of SDRs (ids int32, optional UnitData float payloads)."""
+
+    def __init__(self, device: int = 0, width: int = 0, data_kind="empty"):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.device = int(device)
+        self.width = int(width)
+        self.data_kind = _KINDS[data_kind]
+        check(self._lib.sdrb_batch_create(self.device, self.width, self.data_kind, C.byref(self._h)))
+        self.n_rows = 0
+        self.nnz = 0
+        self.max_row_len = 0
+
+    # -- construction -------------------------------------------------------------
+    @classmethod
+    def from_csr(cls, offsets, ids, data=None, *, width: int = 0, device: int = 0, stream=None):
+        b = cls(device, width, "unit" if data is not None else "empty")
+        b.upload(offsets, ids, data, stream=stream)
+        return b
+
+    @classmethod
+    def from_rows(cls, rows: Sequence, *, with_data: bool = False, width: int = 0, device: int = 0):
+        off, ids, data = rows_to_csr(rows, with_data)
+        return cls.from_csr(off, ids, data, width=width, device=device)
+
+    def upload(self, offsets, ids, data=None, *, stream=None) -> None:
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if off.ndim != 1 or off.size < 1:
+            raise ValueError("offsets must be a 1-d array with n_rows+1 entries")
+        if int(off[-1]) != ids.size:
+            raise ValueError("offsets[-1] must equal len(ids)")
+        dptr = None
+        if self.data_kind == DATA_UNIT:
+            if data is None:
+                raise ValueError("UnitData batch needs payloads")
+            data = np.ascontiguousarray(data, dtype=np.float32)
+            if data.size != ids.size:
+                raise ValueError("data and ids differ in length")
+            dptr = data.ctypes.data_as(C.c_void_p)
+        elif data is not None:
+            raise ValueError("EmptyData batch takes no payloads")
+        n_rows = off.size - 1
+        check(self._lib.sdrb_batch_upload_csr(self._h, n_rows, off.ctypes.data_as(C.c_void_p),
+                                              ids.ctypes.data_as(C.c_void_p), dptr,
+                                              _stream_handle(self.device, stream)))
+        self.n_rows = n_rows
+        self.nnz = int(ids.size)
+        mx = C.c_uint32()
+        check(self._lib.sdrb_batch_info(self._h, None, None, None, None, None, C.byref(mx)))
+        self.max_row_len = int(mx.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sdrb_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return self.n_rows
+
+    # -- size ops (SDR.hpp:175-176, 229-230, 257-258, 317-318) -------------------------
+    def _flags(self, swap: bool, algo: Optional[str]) -> int:
+        f = FLAG_SWAP if swap else 0
+        if algo == "merge":
+            f |= FLAG_FORCE_MERGE
+        elif algo == "bitslice":
+            f |= FLAG_FORCE_BITSLICE
+        elif algo is not None:
+            raise ValueError("algo must be None, 'merge' or 'bitslice'")
+        return f
+
+    def _size_op(self, op: int, other: "SDRBatch", swap: bool, out, stream, algo):
+        torch = _torch()
+        if out is None:
+            out = torch.empty((self.n_rows, other.n_rows), dtype=torch.int32,
+                              device=f"cuda:{other.device}")
+        if out.dtype != torch.int32 or out.dim() != 2 or out.shape[0] < self.n_rows \
+                or out.shape[1] < other.n_rows or out.stride(1) != 1:
+            raise ValueError("out must be an int32 [>=na, >=nb] tensor with unit inner stride")
+        check(self._lib.sdrb_size_op(self._h, other._h, op, self._flags(swap, algo),
+                                     out.data_ptr(), out.stride(0),
+                                     _stream_handle(other.device, stream)))
+        return out
+
+    def ands(self, other, *, swap=False, out=None, stream=None, algo=None):
+        """``out[i, j] = self[i].ands(other[j])`` (uint32 counts in an int32 tensor)."""
+        return self._size_op(OP_AND, other, swap, out, stream, algo)
+
+    def ors(self, other, *, swap=False, out=None, stream=None, algo=None):
+        return self._size_op(OP_OR, other, swap, out, stream, algo)
+
+    def xors(self, other, *, swap=False, out=None, stream=None, algo=None):
+        return self._size_op(OP_XOR, other, swap, out, stream, algo)
+
+    def rms(self, other, *, swap=False, out=None, stream=None, algo=None):
+        return self._size_op(OP_RM, other, swap, out, stream, algo)
+
+    # -- element ops (SDR.hpp:151-152, 209-212, 237-240, 292-293) ---------------------
+    def _elem_op(self, op: int, other: "SDRBatch", swap: bool, stream, algo) -> ElemResult:
+        torch = _torch()
+        dev = f"cuda:{other.device}"
+        pairs = self.n_rows * other.n_rows
+        s = _stream_handle(other.device, stream)
+        offsets = torch.empty(pairs + 1, dtype=torch.int32, device=dev)
+        total = C.c_uint64()
+        flags = self._flags(swap, algo)
+        check(self._lib.sdrb_elem_op_count(self._h, other._h, op, flags, offsets.data_ptr(),
+                                           C.byref(total), s))
+        n = int(total.value)
+        ids = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+        this_kind = other.data_kind if swap else self.data_kind
+        data = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n] if this_kind == DATA_UNIT else None
+        check(self._lib.sdrb_elem_op_fill(self._h, other._h, op, flags, offsets.data_ptr(),
+                                          ids.data_ptr(), data.data_ptr() if data is not None else None, s))
+        return ElemResult(self.n_rows, other.n_rows, offsets, ids, data, n)
+
+    def ande(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
+        return self._elem_op(OP_AND, other, swap, stream, algo)
+
+    def ore(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
+        return self._elem_op(OP_OR, other, swap, stream, algo)
+
+    def xore(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
+        return self._elem_op(OP_XOR, other, swap, stream, algo)
+
+    def rme(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
+        return self._elem_op(OP_RM, other, swap, stream, algo)
+
+
+def synth_csr(seed: int, first_row: int, n_rows: int, width: int, active: int, with_data: bool = False):
+    """Deterministic synthetic rows (see ``sdrb_synth_csr`` in ``include/sdr_amd.h``)."""
+    lib = _lib.load()
+    off = np.empty(n_rows + 1, dtype=np.uint64)
+    ids = np.empty(n_rows * active, dtype=np.int32)
+    data = np.empty(n_rows * active, dtype=np.float32) if with_data else None
+    check(lib.sdrb_synth_csr(seed, first_row, n_rows, width, active, off.ctypes.data_as(C.c_void_p),
+                             ids.ctypes.data_as(C.c_void_p),
+                             data.ctypes.data_as(C.c_void_p) if with_data else None))
+    return off, ids, data

@@ -1,0 +1,460 @@
+// extern "C" boundary of the engine: batch packing into HBM, kernel selection, memory
+// helpers.  No exceptions cross this layer; every entry point returns a status code.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+thread_local std::string g_error;
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct Scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_ws_mutex;
+std::map<std::pair<int, int>, Scratch> g_ws;
+
+void free_batch_storage(sdrb_batch* b) {
+    if (b->d_offsets) (void)hipFree(b->d_offsets);
+    if (b->d_ids) (void)hipFree(b->d_ids);
+    if (b->d_data) (void)hipFree(b->d_data);
+    b->d_offsets = nullptr;
+    b->d_ids = nullptr;
+    b->d_data = nullptr;
+    b->n_rows = 0;
+    b->nnz = 0;
+    b->max_row_len = 0;
+    b->min_id = 0;
+    b->max_id = -1;
+}
+
+bool valid_op(int op) { return op >= SDRB_OP_AND && op <= SDRB_OP_RM; }
+
+// Do the ids alone decide the result of a size op?  `this` EmptyData ignores every payload
+// (EmptyData.hpp:44-80) and ors never looks at payloads (SDR.hpp:1298-1301).
+bool id_only(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
+    const sdrb_batch* self = swap ? b : a;
+    return op == SDRB_OP_OR || self->data_kind == SDRB_DATA_EMPTY;
+}
+
+int check_pair(const sdrb_batch* a, const sdrb_batch* b, int op) {
+    if (!a || !b) {
+        set_error("null batch handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (!valid_op(op)) {
+        set_error("unknown op %d", op);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (a->device != b->device) {
+        set_error("batches live on different devices (%d vs %d)", a->device, b->device);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (!a->d_offsets || !b->d_offsets) {
+        set_error("batch has no uploaded rows");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    return SDRB_OK;
+}
+
+}  // namespace
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+void* workspace(int device, int slot, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Scratch& s = g_ws[{device, slot}];
+    if (s.bytes >= bytes && s.ptr) return s.ptr;
+    if (s.ptr) {
+        // earlier kernels on any stream may still read the old block
+        (void)hipDeviceSynchronize();
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    hipError_t e = hipMalloc(&s.ptr, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) for workspace failed: %s", want, hipGetErrorString(e));
+        s.ptr = nullptr;
+        return nullptr;
+    }
+    s.bytes = want;
+    return s.ptr;
+}
+
+}  // namespace sdrb
+
+using namespace sdrb;
+
+extern "C" {
+
+const char* sdrb_last_error(void) { return g_error.c_str(); }
+
+int sdrb_device_count(int* count) {
+    if (!count) return SDRB_ERR_INVALID_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return SDRB_ERR_HIP;
+    }
+    *count = n;
+    return SDRB_OK;
+}
+
+int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out) {
+    if (!out || width < 0 || device < 0 ||
+        (data_kind != SDRB_DATA_EMPTY && data_kind != SDRB_DATA_UNIT)) {
+        set_error("sdrb_batch_create: bad argument (device=%d width=%d data_kind=%d)", device, width,
+                  data_kind);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    sdrb_batch* b = new (std::nothrow) sdrb_batch();
+    if (!b) {
+        set_error("out of host memory");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    b->device = device;
+    b->width = width;
+    b->data_kind = data_kind;
+    *out = b;
+    return SDRB_OK;
+}
+
+int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
+                          const int32_t* ids, const float* data, void* stream) {
+    if (!batch || !row_offsets) {
+        set_error("sdrb_batch_upload_csr: null argument");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (row_offsets[0] != 0) {
+        set_error("row_offsets[0] must be 0");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const uint64_t nnz = row_offsets[n_rows];
+    if (nnz > 0xFFFFFFFFull || n_rows > 0xFFFFFFFEull) {
+        set_error("batch too large for 32-bit offsets (%llu rows, %llu elements)",
+                  (unsigned long long)n_rows, (unsigned long long)nnz);
+        return SDRB_ERR_OVERFLOW;
+    }
+    if (nnz > 0 && !ids) {
+        set_error("ids is null");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const bool unit = batch->data_kind == SDRB_DATA_UNIT;
+    if (unit && nnz > 0 && !data) {
+        set_error("UnitData batch needs a payload array");
+        return SDRB_ERR_INVALID_ARG;
+    }
+
+    // validate rows and narrow the offsets
+    std::vector<uint32_t> off32(n_rows + 1);
+    uint32_t max_len = 0;
+    int32_t min_id = 0, max_id = -1;
+    bool any = false;
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        const uint64_t lo = row_offsets[r], hi = row_offsets[r + 1];
+        if (hi < lo || hi > nnz) {
+            set_error("row_offsets not monotone at row %llu", (unsigned long long)r);
+            return SDRB_ERR_INVALID_ARG;
+        }
+        off32[r] = (uint32_t)lo;
+        const uint64_t len = hi - lo;
+        if (len > max_len) max_len = (uint32_t)len;
+        for (uint64_t k = lo; k < hi; ++k) {
+            if (k > lo && ids[k] <= ids[k - 1]) {
+                set_error("row %llu is not strictly ascending at element %llu (%d after %d)",
+                          (unsigned long long)r, (unsigned long long)(k - lo), ids[k], ids[k - 1]);
+                return SDRB_ERR_NOT_ASCENDING;
+            }
+        }
+        if (len) {
+            const int32_t first = ids[lo], last = ids[hi - 1];
+            if (!any || first < min_id) min_id = first;
+            if (!any || last > max_id) max_id = last;
+            any = true;
+        }
+    }
+    off32[n_rows] = (uint32_t)nnz;
+    if (batch->width > 0 && any && (min_id < 0 || max_id >= batch->width)) {
+        set_error("id outside the declared width: ids span [%d, %d], width %d", min_id, max_id,
+                  batch->width);
+        return SDRB_ERR_ID_RANGE;
+    }
+    if (unit) {
+        for (uint64_t k = 0; k < nnz; ++k) {
+            if (!(data[k] >= 0.0f && data[k] <= 1.0f)) {
+                set_error("UnitData payload %g at element %llu is outside [0,1]", (double)data[k],
+                          (unsigned long long)k);
+                return SDRB_ERR_PAYLOAD_RANGE;
+            }
+        }
+    }
+
+    DeviceGuard guard(batch->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", batch->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    free_batch_storage(batch);
+    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
+    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_ids), nnz * sizeof(int32_t)));
+    if (nnz && unit) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_data), nnz * sizeof(float)));
+    SDRB_HIP(hipMemcpyAsync(batch->d_offsets, off32.data(), (n_rows + 1) * sizeof(uint32_t),
+                            hipMemcpyHostToDevice, s));
+    if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (nnz && unit)
+        SDRB_HIP(hipMemcpyAsync(batch->d_data, data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    batch->n_rows = n_rows;
+    batch->nnz = nnz;
+    batch->max_row_len = max_len;
+    batch->min_id = min_id;
+    batch->max_id = max_id;
+    return SDRB_OK;
+}
+
+int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint64_t* nnz,
+                    int32_t* width, int* data_kind, uint32_t* max_row_len) {
+    if (!batch) {
+        set_error("null batch handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (device) *device = batch->device;
+    if (n_rows) *n_rows = batch->n_rows;
+    if (nnz) *nnz = batch->nnz;
+    if (width) *width = batch->width;
+    if (data_kind) *data_kind = batch->data_kind;
+    if (max_row_len) *max_row_len = batch->max_row_len;
+    return SDRB_OK;
+}
+
+int sdrb_batch_device_ptrs(const sdrb_batch* batch, const uint32_t** row_offsets,
+                           const int32_t** ids, const float** data) {
+    if (!batch) {
+        set_error("null batch handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (row_offsets) *row_offsets = batch->d_offsets;
+    if (ids) *ids = batch->d_ids;
+    if (data) *data = batch->d_data;
+    return SDRB_OK;
+}
+
+int sdrb_batch_destroy(sdrb_batch* batch) {
+    if (!batch) return SDRB_OK;
+    {
+        DeviceGuard guard(batch->device);
+        free_batch_storage(batch);
+    }
+    delete batch;
+    return SDRB_OK;
+}
+
+int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
+                 uint64_t ld_out, void* stream) {
+    int rc = check_pair(a, b, op);
+    if (rc != SDRB_OK) return rc;
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || ld_out < b->n_rows) {
+        set_error("sdrb_size_op: out is null or ld_out (%llu) < rows of b (%llu)",
+                  (unsigned long long)ld_out, (unsigned long long)b->n_rows);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    const bool can_bitslice = id_only(a, b, op, swap) && bitslice_applicable(a, b);
+    if ((flags & SDRB_FLAG_FORCE_BITSLICE) && !can_bitslice) {
+        set_error("bit-sliced kernel requested but not applicable to these batches/op");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (can_bitslice && !(flags & SDRB_FLAG_FORCE_MERGE))
+        return launch_size_bitslice(a, b, op, swap, out, ld_out, s);
+    return launch_size_merge(a, b, op, swap, out, ld_out, s);
+}
+
+int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                       uint32_t* out_offsets, uint64_t* total, void* stream) {
+    int rc = check_pair(a, b, op);
+    if (rc != SDRB_OK) return rc;
+    if (!out_offsets || !total) {
+        set_error("sdrb_elem_op_count: null output");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const uint64_t pairs = a->n_rows * b->n_rows;
+    if (pairs >= 0xFFFFFFFFull) {
+        set_error("too many pairs for one call (%llu)", (unsigned long long)pairs);
+        return SDRB_ERR_OVERFLOW;
+    }
+    // an upper bound of the total keeps the 32-bit scan exact
+    const bool swap_sides = (flags & SDRB_FLAG_SWAP) != 0;
+    const uint64_t from_a = a->nnz * b->n_rows, from_b = b->nnz * a->n_rows;
+    uint64_t bound;
+    if (op == SDRB_OP_AND) bound = from_a < from_b ? from_a : from_b;
+    else if (op == SDRB_OP_RM) bound = swap_sides ? from_b : from_a;
+    else bound = from_a + from_b;
+    if (bound > 0xFFFFFFFFull) {
+        set_error("result may exceed 2^32-1 elements (bound %llu); split the A batch",
+                  (unsigned long long)bound);
+        return SDRB_ERR_OVERFLOW;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pairs) {
+        rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE), out_offsets,
+                          b->n_rows, stream);
+        if (rc != SDRB_OK) return rc;
+    }
+    SDRB_HIP(hipMemsetAsync(out_offsets + pairs, 0, sizeof(uint32_t), s));
+    rc = launch_exclusive_scan_u32(b->device, out_offsets, pairs + 1, s);
+    if (rc != SDRB_OK) return rc;
+    uint32_t t32 = 0;
+    SDRB_HIP(hipMemcpyAsync(&t32, out_offsets + pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    *total = t32;
+    return SDRB_OK;
+}
+
+int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                      const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
+    int rc = check_pair(a, b, op);
+    if (rc != SDRB_OK) return rc;
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    const sdrb_batch* self = swap ? b : a;
+    if (!out_offsets || !out_ids || (self->data_kind == SDRB_DATA_UNIT && !out_data)) {
+        set_error("sdrb_elem_op_fill: null output (UnitData results need out_data)");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids, out_data,
+                            static_cast<hipStream_t>(stream));
+}
+
+int sdrb_malloc(int device, size_t bytes, void** ptr) {
+    if (!ptr) return SDRB_ERR_INVALID_ARG;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", device);
+        return SDRB_ERR_HIP;
+    }
+    SDRB_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    return SDRB_OK;
+}
+
+int sdrb_free(int device, void* ptr) {
+    if (!ptr) return SDRB_OK;
+    DeviceGuard guard(device);
+    SDRB_HIP(hipFree(ptr));
+    return SDRB_OK;
+}
+
+int sdrb_memcpy_h2d(int device, void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+    DeviceGuard guard(device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (bytes) SDRB_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    return SDRB_OK;
+}
+
+int sdrb_memcpy_d2h(int device, void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+    DeviceGuard guard(device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (bytes) SDRB_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    return SDRB_OK;
+}
+
+int sdrb_stream_sync(int device, void* stream) {
+    DeviceGuard guard(device);
+    SDRB_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return SDRB_OK;
+}
+
+int sdrb_synth_csr(uint64_t seed, uint64_t first_row, uint64_t n_rows, int32_t width,
+                   int32_t active, uint64_t* row_offsets, int32_t* ids, float* data) {
+    if (width <= 0 || active < 0 || active > width || !row_offsets || (!ids && n_rows && active)) {
+        set_error("sdrb_synth_csr: bad argument (width=%d active=%d)", width, active);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+    std::vector<int32_t> perm(width);
+    for (int32_t w = 0; w < width; ++w) perm[w] = w;
+    std::vector<int32_t> swapped(active);
+    for (uint64_t k = 0; k < n_rows; ++k) {
+        const uint64_t r = first_row + k;
+        uint64_t state = seed ^ (r * kGolden);
+        auto next = [&state]() {
+            state += kGolden;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        for (int32_t i = 0; i < active; ++i) {
+            const int32_t jx = i + (int32_t)(next() % (uint64_t)(width - i));
+            swapped[i] = jx;
+            std::swap(perm[i], perm[jx]);
+        }
+        int32_t* row = ids + k * (uint64_t)active;
+        for (int32_t i = 0; i < active; ++i) row[i] = perm[i];
+        // undo the swaps so perm is the identity again for the next row
+        for (int32_t i = active - 1; i >= 0; --i) std::swap(perm[i], perm[swapped[i]]);
+        std::sort(row, row + active);
+        if (data) {
+            float* drow = data + k * (uint64_t)active;
+            for (int32_t i = 0; i < active; ++i) drow[i] = (float)(next() >> 40) * 0x1p-24f;
+        }
+        row_offsets[k] = k * (uint64_t)active;
+    }
+    row_offsets[n_rows] = n_rows * (uint64_t)active;
+    return SDRB_OK;
+}
+
+}  // extern "C"

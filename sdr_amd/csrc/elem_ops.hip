@@ -1,0 +1,221 @@
+// Element operations ande/ore/xore/rme over every pair of two batches:
+// count (a size op) -> exclusive scan -> fill.  This file holds the scan and the fill.
+//
+// Fill: one lane owns pair (i, j) and walks row i of A against row j of B with the
+// three-way merge of the reference's union visitor orv (SDR.hpp:1099-1150), emitting
+//   ande: kept matches only                                  (SDR.hpp:1015-1021)
+//   ore : this-only, converted arg-only, every match          (SDR.hpp:1207-1217)
+//   xore: this-only, converted arg-only, kept matches         (SDR.hpp:1332-1344)
+//   rme : this-only and kept matches                          (SDR.hpp:1540-1560)
+// in ascending id order at the offset the scan assigned to the pair.  An arg-only element
+// is converted to the result's element type (SDRElem.hpp:29-30): an EmptyData argument
+// becomes UnitData 1.0 (UnitData.hpp:13-14), a UnitData argument loses its payload in an
+// EmptyData result (EmptyData.hpp:25-27).
+#include "sdrb_device.h"
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kScanPerThread = 8;
+constexpr int kScanPerBlock = kBlock * kScanPerThread;
+
+// In-place exclusive scan of one 2048-element chunk per block; block totals to `sums`.
+__global__ __launch_bounds__(kBlock) void k_scan_chunks(uint32_t* __restrict__ data, uint64_t n,
+                                                        uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanPerBlock + (uint64_t)threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint64_t idx = base + k;
+        const uint32_t x = idx < n ? data[idx] : 0u;
+        v[k] = run;
+        run += x;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+        if (w < wave) wave_base += wave_tot[w];
+    const uint32_t thread_base = wave_base + incl - run;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint64_t idx = base + k;
+        if (idx < n) data[idx] = v[k] + thread_base;
+    }
+    if (threadIdx.x == kBlock - 1) sums[blockIdx.x] = thread_base + run;
+}
+
+__global__ __launch_bounds__(kBlock) void k_add_chunk_base(uint32_t* __restrict__ data, uint64_t n,
+                                                           const uint32_t* __restrict__ sums) {
+    const uint32_t add = sums[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanPerBlock + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint64_t idx = base + (uint64_t)k * kBlock;
+        if (idx < n) data[idx] += add;
+    }
+}
+
+int scan_level(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t stream) {
+    const uint64_t nchunks = (n + kScanPerBlock - 1) / kScanPerBlock;
+    hipLaunchKernelGGL(k_scan_chunks, dim3((uint32_t)nchunks), dim3(kBlock), 0, stream, data, n, sums);
+    SDRB_HIP(hipGetLastError());
+    if (nchunks > 1) {
+        int rc = scan_level(sums, nchunks, sums + nchunks, stream);
+        if (rc != SDRB_OK) return rc;
+        hipLaunchKernelGGL(k_add_chunk_base, dim3((uint32_t)nchunks), dim3(kBlock), 0, stream, data, n, sums);
+        SDRB_HIP(hipGetLastError());
+    }
+    return SDRB_OK;
+}
+
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+__global__ __launch_bounds__(kBlock) void k_elem_fill(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids,
+    const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
+    const uint32_t* __restrict__ out_off, int32_t* __restrict__ out_ids,
+    float* __restrict__ out_data) {
+    constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
+    constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
+    constexpr bool KEEP_THIS_ONLY = OP != SDRB_OP_AND;
+    constexpr bool KEEP_ARG_ONLY = OP == SDRB_OP_OR || OP == SDRB_OP_XOR;
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= nb) return;
+    const uint32_t b_beg = b_off[j];
+    const uint32_t lb = b_off[j + 1] - b_beg;
+    const int32_t* bi = b_ids + b_beg;
+    const float* bd = B_UNIT ? b_data + b_beg : nullptr;
+
+    for (uint64_t i = blockIdx.y; i < na; i += gridDim.y) {
+        const uint32_t a_beg = a_off[i];
+        const uint32_t la = a_off[i + 1] - a_beg;
+        const int32_t* ai = a_ids + a_beg;
+        const float* ad = A_UNIT ? a_data + a_beg : nullptr;
+        uint32_t w = out_off[i * nb + j];
+        auto emit = [&](int32_t id, float d) {
+            out_ids[w] = id;
+            if constexpr (THIS_UNIT) out_data[w] = d;
+            ++w;
+        };
+        // an element present only in A / only in B
+        auto only_a = [&](uint32_t pa) {
+            const float va = A_UNIT ? ad[pa] : 0.0f;
+            if constexpr (!SWAP) {
+                if constexpr (KEEP_THIS_ONLY) emit(ai[pa], va);
+            } else {
+                if constexpr (KEEP_ARG_ONLY) emit(ai[pa], ARG_UNIT ? va : 1.0f);
+            }
+        };
+        auto only_b = [&](uint32_t pb) {
+            const float vb = B_UNIT ? bd[pb] : 0.0f;
+            if constexpr (SWAP) {
+                if constexpr (KEEP_THIS_ONLY) emit(bi[pb], vb);
+            } else {
+                if constexpr (KEEP_ARG_ONLY) emit(bi[pb], ARG_UNIT ? vb : 1.0f);
+            }
+        };
+        uint32_t pa = 0, pb = 0;
+        while (pa < la && pb < lb) {
+            const int32_t x = ai[pa];
+            const int32_t y = bi[pb];
+            if (x == y) {
+                const float va = A_UNIT ? ad[pa] : 0.0f;
+                const float vb = B_UNIT ? bd[pb] : 0.0f;
+                const float d = SWAP ? match_data<OP, ARG_UNIT>(vb, va) : match_data<OP, ARG_UNIT>(va, vb);
+                if (match_kept<OP, THIS_UNIT>(d)) emit(x, d);
+                ++pa;
+                ++pb;
+            } else if (x < y) {
+                only_a(pa++);
+            } else {
+                only_b(pb++);
+            }
+        }
+        if constexpr (SWAP ? KEEP_ARG_ONLY : KEEP_THIS_ONLY) {
+            while (pa < la) only_a(pa++);
+        }
+        if constexpr (SWAP ? KEEP_THIS_ONLY : KEEP_ARG_ONLY) {
+            while (pb < lb) only_b(pb++);
+        }
+    }
+}
+
+struct FillArgs {
+    const sdrb_batch* a;
+    const sdrb_batch* b;
+    const uint32_t* out_off;
+    int32_t* out_ids;
+    float* out_data;
+    hipStream_t stream;
+};
+
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+void launch(const FillArgs& g) {
+    const uint32_t gx = (uint32_t)((g.b->n_rows + kBlock - 1) / kBlock);
+    const uint32_t gy = (uint32_t)(g.a->n_rows < 65535 ? g.a->n_rows : 65535);
+    hipLaunchKernelGGL((k_elem_fill<OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
+                       g.a->d_offsets, g.a->d_ids, g.a->d_data, g.a->n_rows, g.b->d_offsets,
+                       g.b->d_ids, g.b->d_data, g.b->n_rows, g.out_off, g.out_ids, g.out_data);
+}
+
+template <int OP, bool SWAP>
+void launch_kinds(const FillArgs& g) {
+    const bool au = g.a->data_kind == SDRB_DATA_UNIT, bu = g.b->data_kind == SDRB_DATA_UNIT;
+    if (au && bu) launch<OP, SWAP, true, true>(g);
+    else if (au) launch<OP, SWAP, true, false>(g);
+    else if (bu) launch<OP, SWAP, false, true>(g);
+    else launch<OP, SWAP, false, false>(g);
+}
+
+template <int OP>
+void launch_swap(const FillArgs& g, bool swap) {
+    if (swap) launch_kinds<OP, true>(g);
+    else launch_kinds<OP, false>(g);
+}
+
+}  // namespace
+
+int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream) {
+    if (n == 0) return SDRB_OK;
+    // block sums of every recursion level, laid out back to back
+    uint64_t total_sums = 0;
+    for (uint64_t m = n; m > 1;) {
+        m = (m + kScanPerBlock - 1) / kScanPerBlock;
+        total_sums += m;
+        if (m == 1) break;
+    }
+    uint32_t* sums = static_cast<uint32_t*>(workspace(device, 1, (total_sums + 1) * sizeof(uint32_t)));
+    if (!sums) return SDRB_ERR_HIP;
+    return scan_level(data, n, sums, stream);
+}
+
+int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
+                     hipStream_t stream) {
+    FillArgs g{a, b, out_offsets, out_ids, out_data, stream};
+    switch (op) {
+    case SDRB_OP_AND: launch_swap<SDRB_OP_AND>(g, swap); break;
+    case SDRB_OP_OR: launch_swap<SDRB_OP_OR>(g, swap); break;
+    case SDRB_OP_XOR: launch_swap<SDRB_OP_XOR>(g, swap); break;
+    case SDRB_OP_RM: launch_swap<SDRB_OP_RM>(g, swap); break;
+    default: set_error("unknown op %d", op); return SDRB_ERR_INVALID_ARG;
+    }
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+}  // namespace sdrb

@@ -1,0 +1,66 @@
+// Internal declarations shared by the C-ABI layer and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/sdr_amd.h"
+
+struct sdrb_batch {
+    int device = 0;
+    int32_t width = 0;     // 0 = undeclared
+    int data_kind = SDRB_DATA_EMPTY;
+    uint64_t n_rows = 0;
+    uint64_t nnz = 0;
+    uint32_t max_row_len = 0;
+    int32_t min_id = 0, max_id = -1;  // over all rows (max_id < min_id when empty)
+    uint32_t* d_offsets = nullptr;    // [n_rows + 1]
+    int32_t* d_ids = nullptr;         // [nnz]
+    float* d_data = nullptr;          // [nnz] or null
+};
+
+namespace sdrb {
+
+void set_error(const char* fmt, ...);
+
+// Per-device scratch that grows on demand and lives until process exit.
+// slot 0: query bit-table; slot 1: scan block sums.
+void* workspace(int device, int slot, size_t bytes);
+
+#define SDRB_HIP(call)                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            sdrb::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                            __FILE__, __LINE__);                                         \
+            return SDRB_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+// How a pair's result depends on payloads, after SDRB_FLAG_SWAP has been applied:
+// `this_unit` / `arg_unit` say whether the `this` / `arg` side carries UnitData.
+struct PairKinds {
+    bool this_unit;
+    bool arg_unit;
+};
+
+// size_bitslice.hip ---------------------------------------------------------------
+// True when the id-only bit-sliced kernel can serve (a as tile side, b as lane side).
+bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b);
+int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                         uint32_t* out, uint64_t ld_out, hipStream_t stream);
+
+// size_merge.hip ------------------------------------------------------------------
+int launch_size_merge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                      uint32_t* out, uint64_t ld_out, hipStream_t stream);
+
+// elem_ops.hip --------------------------------------------------------------------
+int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream);
+int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
+                     hipStream_t stream);
+
+}  // namespace sdrb

@@ -1,0 +1,336 @@
+// Bit-sliced table kernel for the id-only size operations (ands/ors/xors/rms whose result
+// depends on ids alone: `this` side EmptyData, or ors on any payloads).
+//
+// For one pair the reference walks two sorted id lists with andv (SDR.hpp:958-997) and
+// counts the matches (SDR.hpp:1083-1095); every size op is then a function of |this|,
+// |arg| and that count (SDR.hpp:1303, 1433, 1576 with EmptyData.hpp:50-51,70-71,79-80).
+// Here the count for 64 rows of A against one row of B is computed at once:
+//
+//   table[t][w]  (uint64)  bit q set  <=>  row 64*t+q of A contains id w
+//
+// is built once per call (1 MiB for 4096 rows of width 2048).  A lane owns one row j of B,
+// keeps that row's ids in registers as LDS byte offsets, and for each tile t gathers the
+// row's table words from LDS and adds them with carry-save adders into bit planes
+// ("vertical counters"): plane p holds bit p of the 64 match counts.  The planes are then
+// unpacked four counts at a time into bytes and stored as uint32, one 256-byte coalesced
+// store per wave per A row.  Each row of B is read from HBM once; the output write
+// (4 bytes per pair) is the only large stream, so the kernel is bound by HBM write bandwidth.
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+using u64 = unsigned long long;
+
+constexpr int kBlock = 256;
+constexpr int kTileRows = 64;  // rows of A per table tile = bits of one table word
+
+__global__ __launch_bounds__(64) void k_build_table(const uint32_t* __restrict__ a_off,
+                                                     const int32_t* __restrict__ a_ids,
+                                                     int32_t width, uint32_t wstride,
+                                                     u64* __restrict__ table,
+                                                     uint32_t* __restrict__ a_len) {
+    const uint64_t i = blockIdx.x;
+    const uint32_t beg = a_off[i];
+    const uint32_t len = a_off[i + 1] - beg;
+    if (threadIdx.x == 0) a_len[i] = len;
+    u64* tile = table + (i / kTileRows) * (uint64_t)wstride;
+    const u64 bit = 1ull << (i % kTileRows);
+    for (uint32_t k = threadIdx.x; k < len; k += 64) {
+        const int32_t id = a_ids[beg + k];
+        // ids outside B's declared width cannot match any id of B
+        if ((uint32_t)id < (uint32_t)width) atomicOr(&tile[id], bit);
+    }
+}
+
+constexpr int bits_for(int n) {  // bits needed to hold values 0..n
+    int b = 0;
+    while (n > 0) { ++b; n >>= 1; }
+    return b;
+}
+
+// carry-save adder: (h, l) = a + b + c, bitwise over 64 independent counters
+#define SDRB_CSA(h, l, a, b, c)                    \
+    do {                                           \
+        const u64 u_ = (a) ^ (b);                  \
+        const u64 c_ = (c);                        \
+        (h) = (u_ & c_) | (~u_ & (a));             \
+        (l) = u_ ^ c_;                             \
+    } while (0)
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int s) {
+    return __builtin_amdgcn_alignbit(x, x, (uint32_t)(s & 31));
+}
+
+// NCH  : the lane keeps 8*NCH ids of its row in registers (rows are padded with a sentinel
+//        offset that points at an all-zero table word)
+// MODE : 0 -> out = m;  1 -> out = L - m;  2 -> out = L - 2m   (m = id matches,
+//        L = use_la*|A_i| + use_lb*|B_j|)
+// WCAP : table words per tile held in one LDS buffer (two buffers, double buffered)
+template <int NCH, int MODE, int WCAP>
+__global__ __launch_bounds__(kBlock) void k_size_bitslice(
+    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb,
+    const u64* __restrict__ table, const uint32_t* __restrict__ a_len, uint32_t wstride,
+    uint32_t ntiles, uint32_t tiles_per_block, uint64_t na, uint32_t use_la, uint32_t use_lb,
+    uint32_t* __restrict__ out, uint64_t ld_out) {
+    constexpr int NPL = bits_for(8 * NCH);
+    constexpr int SH = MODE == 2 ? 1 : 0;
+    static_assert(NPL + SH <= 8, "counts must fit one byte during unpacking");
+    constexpr int BUF = WCAP + 2;             // words per LDS buffer (sentinel at [wstride])
+    constexpr int PF = WCAP / 2 / kBlock;     // uint4 table loads per thread per tile
+    __shared__ __attribute__((aligned(16))) u64 lds[2 * BUF];
+
+    const uint32_t tid = threadIdx.x;
+    const uint64_t j0 = (uint64_t)blockIdx.x * kBlock;
+    const uint64_t j = j0 + tid;
+    const bool valid = j < nb;
+
+    // this lane's row of B -> LDS byte offsets in registers
+    uint32_t beg = 0, lb = 0;
+    if (valid) {
+        beg = b_off[j];
+        lb = b_off[j + 1] - beg;
+    }
+    uint32_t off[8 * NCH];
+#pragma unroll
+    for (int k = 0; k < 8 * NCH; ++k) {
+        off[k] = wstride * 8u;
+        if ((uint32_t)k < lb) off[k] = (uint32_t)b_ids[beg + k] * 8u;
+    }
+    const uint32_t lbterm = use_lb ? lb : 0u;
+
+    const uint32_t t0 = blockIdx.y * tiles_per_block;
+    const uint32_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
+    if (t0 >= t1) return;
+
+    if (tid == 0) {
+        lds[wstride] = 0;
+        lds[BUF + wstride] = 0;
+    }
+
+    uint4 pf[PF];
+    auto load_tile = [&](uint32_t t) {
+        const uint4* src = reinterpret_cast<const uint4*>(table + (uint64_t)t * wstride);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const uint32_t idx = tid + p * kBlock;
+            if (idx * 2 < wstride) pf[p] = src[idx];
+        }
+    };
+    auto write_tile = [&](int buf) {
+        uint4* dst = reinterpret_cast<uint4*>(lds + buf * BUF);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const uint32_t idx = tid + p * kBlock;
+            if (idx * 2 < wstride) dst[idx] = pf[p];
+        }
+    };
+
+    load_tile(t0);
+    write_tile(0);
+    __syncthreads();
+
+    char* const out_block = reinterpret_cast<char*>(out) + j0 * 4;
+    const uint32_t voff = tid * 4;
+
+    auto process = [&](uint32_t t, auto buf_tag) {
+        constexpr int BUFSEL = decltype(buf_tag)::value;
+        const bool more = t + 1 < t1;
+        if (more) load_tile(t + 1);
+
+        uint32_t la_vec = 0;
+        if constexpr (MODE != 0) {
+            if (use_la) la_vec = a_len[(uint64_t)t * kTileRows + (tid & 63)];
+        }
+
+        // ---- gather + vertical counters
+        const char* base = reinterpret_cast<const char*>(lds + BUFSEL * BUF);
+        u64 P[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) P[p] = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            u64 x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const u64*>(base + off[ch * 8 + k]);
+            u64 t2a, t2b, t4a, t4b, e8;
+            SDRB_CSA(t2a, P[0], P[0], x[0], x[1]);
+            SDRB_CSA(t2b, P[0], P[0], x[2], x[3]);
+            SDRB_CSA(t4a, P[1], P[1], t2a, t2b);
+            SDRB_CSA(t2a, P[0], P[0], x[4], x[5]);
+            SDRB_CSA(t2b, P[0], P[0], x[6], x[7]);
+            SDRB_CSA(t4b, P[1], P[1], t2a, t2b);
+            SDRB_CSA(e8, P[2], P[2], t4a, t4b);
+#pragma unroll
+            for (int p = 3; p < NPL; ++p) {  // ripple the weight-8 carry upwards
+                const u64 nc = P[p] & e8;
+                P[p] ^= e8;
+                e8 = nc;
+            }
+        }
+
+        // ---- unpack 4 counts at a time into bytes, finish the op, store
+        const bool full = ((uint64_t)t + 1) * kTileRows <= na;
+        auto emit = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) {
+                        const uint32_t w = h ? (uint32_t)(P[p] >> 32) : (uint32_t)P[p];
+                        // bits r, r+8, r+16, r+24 of plane p -> bit p+SH of bytes 0..3
+                        acc |= rotr32(w, r - p - SH) & (0x01010101u << (p + SH));
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int q = 32 * h + 8 * c + r;
+                        const uint64_t qi = (uint64_t)t * kTileRows + q;
+                        if (!FULL && qi >= na) continue;
+                        uint32_t v = (acc >> (8 * c)) & 0xffu;
+                        if constexpr (MODE != 0) {
+                            const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)la_vec, q);
+                            v = (la + lbterm) - v;
+                        }
+                        if (valid) *reinterpret_cast<uint32_t*>(out_block + qi * ld_out * 4 + voff) = v;
+                    }
+                }
+            }
+        };
+        if (full) emit(std::true_type{});
+        else emit(std::false_type{});
+
+        if (more) write_tile(BUFSEL ^ 1);
+        __syncthreads();
+    };
+
+    for (uint32_t t = t0; t < t1; t += 2) {
+        process(t, std::integral_constant<int, 0>{});
+        if (t + 1 < t1) process(t + 1, std::integral_constant<int, 1>{});
+    }
+}
+
+struct Plan {
+    int nch;
+    int wcap;
+};
+
+bool make_plan(const sdrb_batch* a, const sdrb_batch* b, Plan* plan) {
+    if (b->width <= 0 || b->width > 4096) return false;
+    if (b->max_row_len > 64) return false;
+    (void)a;
+    plan->nch = b->max_row_len <= 16 ? 2 : b->max_row_len <= 32 ? 4 : b->max_row_len <= 40 ? 5 : 8;
+    plan->wcap = b->width <= 2048 ? 2048 : 4096;
+    return true;
+}
+
+struct Args {
+    const sdrb_batch* a;
+    const sdrb_batch* b;
+    const u64* table;
+    const uint32_t* a_len;
+    uint32_t wstride, ntiles, tiles_per_block, use_la, use_lb;
+    dim3 grid;
+    uint32_t* out;
+    uint64_t ld_out;
+    hipStream_t stream;
+};
+
+template <int NCH, int MODE, int WCAP>
+void launch(const Args& g) {
+    hipLaunchKernelGGL((k_size_bitslice<NCH, MODE, WCAP>), g.grid, dim3(kBlock), 0, g.stream,
+                       g.b->d_offsets, g.b->d_ids, g.b->n_rows, g.table, g.a_len, g.wstride,
+                       g.ntiles, g.tiles_per_block, g.a->n_rows, g.use_la, g.use_lb, g.out,
+                       g.ld_out);
+}
+
+template <int NCH, int MODE>
+void launch_w(const Args& g, int wcap) {
+    if (wcap == 2048) launch<NCH, MODE, 2048>(g);
+    else launch<NCH, MODE, 4096>(g);
+}
+
+template <int MODE>
+void launch_n(const Args& g, const Plan& p) {
+    switch (p.nch) {
+    case 2: launch_w<2, MODE>(g, p.wcap); break;
+    case 4: launch_w<4, MODE>(g, p.wcap); break;
+    case 5: launch_w<5, MODE>(g, p.wcap); break;
+    default: launch_w<8, MODE>(g, p.wcap); break;
+    }
+}
+
+}  // namespace
+
+bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b) {
+    Plan p;
+    return make_plan(a, b, &p);
+}
+
+int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                         uint32_t* out, uint64_t ld_out, hipStream_t stream) {
+    Plan plan;
+    if (!make_plan(a, b, &plan)) {
+        set_error("bit-sliced size kernel not applicable (needs 0 < width <= 4096 and rows <= 64 ids on the streamed batch)");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+
+    Args g;
+    g.a = a;
+    g.b = b;
+    g.wstride = ((uint32_t)b->width + 1u) & ~1u;
+    g.ntiles = (uint32_t)((a->n_rows + kTileRows - 1) / kTileRows);
+    const size_t table_bytes = (size_t)g.ntiles * g.wstride * sizeof(u64);
+    const size_t len_bytes = (size_t)g.ntiles * kTileRows * sizeof(uint32_t);
+    char* ws = static_cast<char*>(workspace(b->device, 0, table_bytes + len_bytes));
+    if (!ws) return SDRB_ERR_HIP;
+    SDRB_HIP(hipMemsetAsync(ws, 0, table_bytes + len_bytes, stream));
+    u64* table = reinterpret_cast<u64*>(ws);
+    uint32_t* a_len = reinterpret_cast<uint32_t*>(ws + table_bytes);
+    hipLaunchKernelGGL(k_build_table, dim3((uint32_t)a->n_rows), dim3(64), 0, stream, a->d_offsets,
+                       a->d_ids, b->width, g.wstride, table, a_len);
+    SDRB_HIP(hipGetLastError());
+    g.table = table;
+    g.a_len = a_len;
+
+    const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
+    uint32_t gy = gx >= 1024 ? 1u : (1024u + gx - 1) / gx;
+    if (gy > g.ntiles) gy = g.ntiles;
+    g.tiles_per_block = (g.ntiles + gy - 1) / gy;
+    gy = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
+    g.grid = dim3(gx, gy);
+    g.out = out;
+    g.ld_out = ld_out;
+    g.stream = stream;
+
+    switch (op) {
+    case SDRB_OP_AND:
+        g.use_la = g.use_lb = 0;
+        launch_n<0>(g, plan);
+        break;
+    case SDRB_OP_OR:
+        g.use_la = g.use_lb = 1;
+        launch_n<1>(g, plan);
+        break;
+    case SDRB_OP_XOR:
+        g.use_la = g.use_lb = 1;
+        launch_n<2>(g, plan);
+        break;
+    case SDRB_OP_RM:  // |this| - matches
+        g.use_la = swap ? 0 : 1;
+        g.use_lb = swap ? 1 : 0;
+        launch_n<1>(g, plan);
+        break;
+    default:
+        set_error("unknown op %d", op);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+}  // namespace sdrb

@@ -1,0 +1,212 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors, bit for bit.  Sizes are kept where the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+import oracle
+import sdr_amd
+import util
+from oracle import AND, OR, RM, XOR, Batch
+from sdr_amd import SDRBatch
+
+pytestmark = pytest.mark.gpu
+
+PAIRINGS = {"EE": (False, False), "UU": (True, True), "UE": (True, False), "EU": (False, True)}
+OPS = {AND: ("ands", "ande"), OR: ("ors", "ore"), XOR: ("xors", "xore"), RM: ("rms", "rme")}
+
+
+def dev(b: Batch, width=0) -> SDRBatch:
+    return SDRBatch.from_csr(b.off, b.ids, b.data, width=width)
+
+
+def gpu_sizes(op, t: SDRBatch, a: SDRBatch, **kw) -> np.ndarray:
+    return getattr(t, OPS[op][0])(a, **kw).cpu().numpy().view(np.uint32)
+
+
+def gpu_elems(op, t: SDRBatch, a: SDRBatch, **kw):
+    return getattr(t, OPS[op][1])(a, **kw).to_host()
+
+
+def id_only(op, this_unit):
+    return op == OR or not this_unit
+
+
+def assert_elems_equal(got, want):
+    assert np.array_equal(got[0], want[0]), "offsets differ"
+    assert np.array_equal(got[1], want[1]), "ids differ"
+    if want[2] is None:
+        assert got[2] is None
+    else:
+        assert np.array_equal(got[2].view(np.uint32), want[2].view(np.uint32)), "payload bits differ"
+
+
+def fuzz_pair(n, name, seed):
+    tu, au = PAIRINGS[name]
+    return (Batch(*util.fuzz_universe(n, seed if tu else None)),
+            Batch(*util.fuzz_universe(n, seed + 1 if au else None)))
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_fuzz_grid_sizes_vs_golden(golden, name):
+    g = golden("fuzz_sizes.npz")
+    t, a = fuzz_pair(256, name, int(g["seed"]))
+    dt, da = dev(t, 8), dev(a, 8)
+    for op in range(4):
+        want = g[name][op].astype(np.uint32)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="merge"), want)
+        assert np.array_equal(gpu_sizes(op, dt, da), want)
+        if id_only(op, PAIRINGS[name][0]):
+            assert np.array_equal(gpu_sizes(op, dt, da, algo="bitslice"), want)
+        else:
+            with pytest.raises(sdr_amd.SdrbError):
+                gpu_sizes(op, dt, da, algo="bitslice")
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_fuzz_grid_elems_vs_golden(golden, name):
+    g = golden("fuzz_elems.npz")
+    seed = int(g["seed"])
+    t, a = fuzz_pair(128, name, seed)
+    dt, da = dev(t, 7), dev(a, 7)
+    for op in range(4):
+        off, ids, data = gpu_elems(op, dt, da)
+        assert np.array_equal(np.diff(off).reshape(128, 128), g[name + "_len"][op])
+        assert np.array_equal(util.pair_digests(off, ids, data).reshape(128, 128), g[name + "_digest"][op])
+    t, a = fuzz_pair(64, name, seed)
+    dt, da = dev(t), dev(a)
+    for op in range(4):
+        off, ids, data = gpu_elems(op, dt, da)
+        assert np.array_equal(off, g[f"{name}_full{op}_off"])
+        assert np.array_equal(ids, g[f"{name}_full{op}_ids"])
+        if data is not None:
+            assert np.array_equal(data.view(np.uint32), g[f"{name}_full{op}_data"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_swap_flag_matches_swapped_roles(name):
+    # swap: result(i, j) = B_j.op(A_i)
+    t, a = fuzz_pair(64, name, 99)
+    dt, da = dev(t, 6), dev(a, 6)
+    for op in range(4):
+        want = oracle.port().size_op(op, a, t).T
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True), want)
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True, algo="merge"), want)
+        off, ids, data = gpu_elems(op, dt, da, swap=True)
+        w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
+        # oracle order is [j][i]; compare pair by pair
+        lens = np.diff(w_off).reshape(a.n, t.n).T
+        assert np.array_equal(np.diff(off).reshape(t.n, a.n), lens)
+        got_d = util.pair_digests(off, ids, data).reshape(t.n, a.n)
+        want_d = util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T
+        assert np.array_equal(got_d, want_d)
+
+
+@pytest.mark.parametrize("width,max_len_b,nq,nd", [
+    (2048, 40, 70, 700), (2048, 10, 64, 256), (300, 30, 1, 513), (2048, 64, 129, 300),
+    (4096, 40, 65, 257), (3001, 16, 5, 100), (2047, 33, 130, 1000)])
+def test_bitslice_ragged_vs_oracle(width, max_len_b, nq, nd):
+    rng = np.random.default_rng(width * 31 + max_len_b)
+    t = Batch(*util.ragged_rows(rng, nq, width, 70))
+    a = Batch(*util.ragged_rows(rng, nd, width, max_len_b))
+    dt, da = dev(t, width), dev(a, width)
+    for op in range(4):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="bitslice"), want)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="merge"), want)
+    want = oracle.port().size_op(RM, a, t).T
+    assert np.array_equal(gpu_sizes(RM, dt, da, swap=True, algo="bitslice"), want)
+
+
+def test_query_ids_beyond_db_width_never_match():
+    rng = np.random.default_rng(5)
+    t = Batch(*util.ragged_rows(rng, 20, 400, 50, lo=-100))  # ids in [-100, 300)
+    a = Batch(*util.ragged_rows(rng, 300, 200, 40))          # ids in [0, 200)
+    dt, da = dev(t), dev(a, 200)
+    for op in range(4):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="bitslice"), want)
+        assert np.array_equal(gpu_sizes(op, dt, da), want)
+
+
+@pytest.mark.parametrize("tu,au", list(PAIRINGS.values()))
+def test_merge_and_elems_ragged_signed_ids(tu, au):
+    rng = np.random.default_rng(11 + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, 37, 500, 90, tu, lo=-250))
+    a = Batch(*util.ragged_rows(rng, 333, 500, 120, au, lo=-250))
+    dt, da = dev(t), dev(a)
+    for op in range(4):
+        assert np.array_equal(gpu_sizes(op, dt, da), oracle.port().size_op(op, t, a))
+        assert_elems_equal(gpu_elems(op, dt, da), oracle.port().elem_op(op, t, a))
+
+
+def test_rows_longer_than_table_kernel_fall_back_to_merge():
+    rng = np.random.default_rng(3)
+    t = Batch(*util.ragged_rows(rng, 9, 1000, 200))
+    a = Batch(*util.ragged_rows(rng, 130, 1000, 200))
+    dt, da = dev(t, 1000), dev(a, 1000)
+    assert a.n and da.max_row_len > 64
+    assert np.array_equal(gpu_sizes(AND, dt, da), oracle.port().size_op(AND, t, a))
+    with pytest.raises(sdr_amd.SdrbError) as e:
+        gpu_sizes(AND, dt, da, algo="bitslice")
+    assert e.value.code == -5
+
+
+def test_empty_and_degenerate_batches():
+    empty = Batch([0], [])
+    some = Batch.from_rows([[], [1, 2, 3], []])
+    de, ds = dev(empty, 8), dev(some, 8)
+    assert gpu_sizes(AND, de, ds).shape == (0, 3)
+    assert gpu_sizes(AND, ds, de).shape == (3, 0)
+    for op in range(4):
+        for algo in (None, "merge", "bitslice"):
+            assert np.array_equal(gpu_sizes(op, ds, ds, algo=algo), oracle.port().size_op(op, some, some))
+        assert_elems_equal(gpu_elems(op, ds, ds), oracle.port().elem_op(op, some, some))
+        off, ids, data = gpu_elems(op, de, ds)
+        assert off.tolist() == [0] and ids.size == 0
+
+
+def test_leading_dimension_and_partial_tiles():
+    import torch
+    rng = np.random.default_rng(21)
+    t = Batch(*util.ragged_rows(rng, 67, 2048, 40))
+    a = Batch(*util.ragged_rows(rng, 1000, 2048, 40))
+    dt, da = dev(t, 2048), dev(a, 2048)
+    out = torch.full((70, 1100), -7, dtype=torch.int32, device="cuda:0")
+    dt.ands(da, out=out)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:67, :1000].view(np.uint32), oracle.port().size_op(AND, t, a))
+    assert (got[67:, :] == -7).all() and (got[:, 1000:] == -7).all()
+
+
+@pytest.mark.parametrize("fname", ["mini_2048_40.npz", "mini_16k_328.npz"])
+def test_config_shaped_minis_vs_golden(golden, fname):
+    g = golden(fname)
+    nq, nd, width, active = int(g["nq"]), int(g["nd"]), int(g["width"]), int(g["active"])
+    wd = bool(g["with_data"])
+    q = SDRBatch.from_csr(*sdr_amd.synth_csr(2, 0, nq, width, active, wd), width=width)
+    d = SDRBatch.from_csr(*sdr_amd.synth_csr(1, 0, nd, width, active, wd), width=width)
+    for op in range(4):
+        assert np.array_equal(gpu_sizes(op, q, d), g["sizes"][op])
+        off, ids, data = gpu_elems(op, q, d)
+        assert np.array_equal(np.diff(off).reshape(nq, nd), g[f"len{op}"])
+        assert np.array_equal(util.pair_digests(off, ids, data).reshape(nq, nd), g[f"digest{op}"])
+        assert np.array_equal(ids[: int(off[1])], g[f"pair00_ids{op}"])
+        if wd:
+            assert np.array_equal(data[: int(off[1])].view(np.uint32), g[f"pair00_data{op}"].view(np.uint32))
+
+
+def test_readme_examples_on_device():
+    a = SDRBatch.from_rows([[1, 2]])
+    b = SDRBatch.from_rows([[2, 3]])
+    assert a.ande(b).to_host()[1].tolist() == [2]          # README.md:65-70
+    assert a.ore(b).to_host()[1].tolist() == [1, 2, 3]
+    assert a.xore(b).to_host()[1].tolist() == [1, 3]
+    assert a.rme(b).to_host()[1].tolist() == [1]
+    assert int(a.ands(b)[0, 0]) == 1                         # README.md:79-90
+    u = SDRBatch.from_rows([([0], [0.5])], with_data=True)
+    off, ids, data = u.ande(u).to_host()                     # README.md:113-116
+    assert ids.tolist() == [0] and data.tolist() == [0.25]
+    q = SDRBatch.from_rows([([0], [0.25])], with_data=True)
+    assert q.ande(q).total == 0 and int(q.ands(q)[0, 0]) == 0  # README.md:120-123
+    off, ids, data = u.ande(SDRBatch.from_rows([[0]])).to_host()  # README.md:127-128
+    assert ids.tolist() == [0] and data.tolist() == [0.5]

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REAL reference (oracle/_ref/libsdr_ref_dbg.so, i.e.
+jagprog5/SDR's own headers compiled with asserts on).  Run from the repo root in a
+container that has /root/reference:
+
+    make -C oracle && python tools/gen_golden.py
+
+The fixtures hold inputs and expected outputs only.  While generating, the plain-C
+restatement (oracle/sdr_oracle.c) is required to agree with the reference on every value
+written -- that is what pins the oracle.
+
+Fixtures
+  fuzz_sizes.npz    exhaustive fuzz grid of src/fuzz.cpp:236-252 on an 8-id universe:
+                    for all 256x256 pairs, the four size ops (uint8) for the payload pairings
+                    EE, UU, UE, EU (this x arg; E = EmptyData, U = UnitData).
+  fuzz_elems.npz    element ops on the 7-id universe (128x128 pairs): result lengths and
+                    32-bit digests of every result (tests/util.py:pair_digests), plus the
+                    complete results of the 6-id universe (64x64 pairs) as CSR.
+  mini_2048_40.npz  config-shaped: 8 queries x 4096 rows, width 2048 / 40 active, EmptyData:
+                    sizes + element-op lengths and digests.
+  mini_16k_328.npz  4 queries x 512 rows, width 16384 / 328 active, UnitData x UnitData.
+  inplace.npz       andi/ori/xori/rmi on a 5-id universe incl. the aliased a.op(a) cases.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle  # noqa: E402
+import util  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FUZZ_SEED = 20240607
+PAIRINGS = {"EE": (None, None), "UU": (FUZZ_SEED, FUZZ_SEED + 1), "UE": (FUZZ_SEED, None),
+            "EU": (None, FUZZ_SEED + 1)}
+
+
+def both(fn_name, *args):
+    """Runs the entry point on the reference and on the restatement; they must agree."""
+    ref = getattr(oracle.reference(debug=True), fn_name)(*args)
+    mine = getattr(oracle.port(), fn_name)(*args)
+    if isinstance(ref, tuple):
+        for r, m in zip(ref, mine):
+            assert (r is None and m is None) or np.array_equal(r, m), fn_name
+    else:
+        assert np.array_equal(ref, mine), fn_name
+    return ref
+
+
+def fuzz_batches(n, pairing):
+    ts, as_ = PAIRINGS[pairing]
+    return oracle.Batch(*util.fuzz_universe(n, ts)), oracle.Batch(*util.fuzz_universe(n, as_))
+
+
+def gen_fuzz_sizes():
+    out = {}
+    for name in PAIRINGS:
+        t, a = fuzz_batches(256, name)
+        sizes = np.stack([both("size_op", op, t, a) for op in range(4)])
+        assert sizes.max() < 256
+        out[name] = sizes.astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "fuzz_sizes.npz"), seed=FUZZ_SEED, **out)
+
+
+def gen_fuzz_elems():
+    out = {}
+    for name in PAIRINGS:
+        t, a = fuzz_batches(128, name)
+        lens, digs = [], []
+        for op in range(4):
+            off, ids, data = both("elem_op", op, t, a)
+            lens.append(np.diff(off).astype(np.uint8).reshape(128, 128))
+            digs.append(util.pair_digests(off, ids, data).reshape(128, 128))
+        out[name + "_len"] = np.stack(lens)
+        out[name + "_digest"] = np.stack(digs)
+        t, a = fuzz_batches(64, name)
+        for op in range(4):
+            off, ids, data = both("elem_op", op, t, a)
+            out[f"{name}_full{op}_off"] = off.astype(np.uint32)
+            out[f"{name}_full{op}_ids"] = ids.astype(np.int8)
+            if data is not None:
+                out[f"{name}_full{op}_data"] = data
+    np.savez_compressed(os.path.join(OUT, "fuzz_elems.npz"), seed=FUZZ_SEED, **out)
+
+
+def gen_mini(fname, nq, nd, width, active, with_data):
+    # db seed 1, query seed 2; independent numpy statement of the generator
+    q = oracle.Batch(*util.synth_rows_numpy(2, 0, nq, width, active, with_data))
+    d = oracle.Batch(*util.synth_rows_numpy(1, 0, nd, width, active, with_data))
+    out = dict(nq=nq, nd=nd, width=width, active=active, with_data=with_data,
+               q_ids_head=q.ids[:active].copy(), d_ids_head=d.ids[:active].copy())
+    if with_data:
+        out["q_data_head"] = q.data[:active].copy()
+        out["d_data_head"] = d.data[:active].copy()
+    out["sizes"] = np.stack([both("size_op", op, q, d) for op in range(4)]).astype(np.uint16)
+    for op in range(4):
+        off, ids, data = both("elem_op", op, q, d)
+        out[f"len{op}"] = np.diff(off).astype(np.uint16).reshape(nq, nd)
+        out[f"digest{op}"] = util.pair_digests(off, ids, data).reshape(nq, nd)
+        # the complete result of pair (0, 0)
+        out[f"pair00_ids{op}"] = ids[: int(off[1])].copy()
+        if data is not None:
+            out[f"pair00_data{op}"] = data[: int(off[1])].copy()
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_inplace():
+    ref = oracle.reference(debug=True)
+    out = {}
+    n = 32
+    for name in PAIRINGS:
+        t, a = fuzz_batches(n, name)
+        for op in range(4):
+            off, ids, data = ref.elem_op(op, t, a, inplace=True)
+            # restatement, pair by pair
+            k = 0
+            for i in range(n):
+                ti, td = t.row(i)
+                for j in range(n):
+                    ai, ad = a.row(j)
+                    r_ids, r_data = oracle.port_inplace(op, ti, td, ai, ad)
+                    lo, hi = int(off[k]), int(off[k + 1])
+                    assert np.array_equal(r_ids, ids[lo:hi]), (name, op, i, j)
+                    if data is not None:
+                        assert np.array_equal(r_data, data[lo:hi]), (name, op, i, j)
+                    k += 1
+            out[f"{name}_len{op}"] = np.diff(off).astype(np.uint8).reshape(n, n)
+            out[f"{name}_digest{op}"] = util.pair_digests(off, ids, data).reshape(n, n)
+    # aliasing: a.op(a) with the same object on both sides (src/test.cpp:241-272)
+    for kind, seed in (("E", None), ("U", FUZZ_SEED)):
+        u = oracle.Batch(*util.fuzz_universe(n, seed))
+        for op in range(4):
+            lens, digs = [], []
+            for i in range(n):
+                ids, data = u.row(i)
+                buf_ids = np.zeros(2 * len(ids) + 1, dtype=np.int32)
+                buf_ids[: len(ids)] = ids
+                buf_data = np.zeros(2 * len(ids) + 1, dtype=np.float32)
+                if data is not None:
+                    buf_data[: len(ids)] = data
+                ln = ref.lib.rsdr_inplace_self(op, buf_ids.ctypes.data, buf_data.ctypes.data, len(ids),
+                                               oracle.UNIT if data is not None else oracle.EMPTY)
+                p_ids, p_data = oracle.port_inplace(op, ids, data, None, None, alias=True)
+                assert np.array_equal(p_ids, buf_ids[:ln]), (kind, op, i)
+                if data is not None:
+                    assert np.array_equal(p_data, buf_data[:ln]), (kind, op, i)
+                lens.append(ln)
+                digs.append(util.pair_digests(np.array([0, ln], dtype=np.uint64), buf_ids[:ln],
+                                              buf_data[:ln] if data is not None else None)[0])
+            out[f"alias_{kind}_len{op}"] = np.asarray(lens, dtype=np.uint8)
+            out[f"alias_{kind}_digest{op}"] = np.asarray(digs, dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "inplace.npz"), seed=FUZZ_SEED, **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    if not oracle.have_reference():
+        sys.exit("oracle/_ref is not built: this script needs /root/reference (make -C oracle)")
+    gen_fuzz_sizes()
+    gen_fuzz_elems()
+    gen_mini("mini_2048_40.npz", 8, 4096, 2048, 40, False)
+    gen_mini("mini_16k_328.npz", 4, 512, 16384, 328, True)
+    gen_inplace()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
