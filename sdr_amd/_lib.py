@@ -69,6 +69,14 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `make -C sdr_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
             )
+        # A process must hold ONE HIP runtime.  torch wheels bundle their own libamdhip64
+        # (same soname as /opt/rocm's); importing torch first makes the loader resolve this
+        # library's libamdhip64.so.7 to the copy torch already mapped, so stream handles and
+        # device pointers are shared.  Without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in PROTOTYPES.items():
             fn = getattr(lib, name)

@@ -188,11 +188,15 @@ class SDRBatch:
         check(self._lib.sdrb_elem_op_count(self._h, other._h, op, flags, offsets.data_ptr(),
                                            C.byref(total), s))
         n = int(total.value)
-        ids = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+        # buffers keep at least one element so an empty result still has a valid pointer
+        ids_buf = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         this_kind = other.data_kind if swap else self.data_kind
-        data = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n] if this_kind == DATA_UNIT else None
+        data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if this_kind == DATA_UNIT else None
         check(self._lib.sdrb_elem_op_fill(self._h, other._h, op, flags, offsets.data_ptr(),
-                                          ids.data_ptr(), data.data_ptr() if data is not None else None, s))
+                                          ids_buf.data_ptr(),
+                                          data_buf.data_ptr() if data_buf is not None else None, s))
+        ids = ids_buf[:n]
+        data = data_buf[:n] if data_buf is not None else None
         return ElemResult(self.n_rows, other.n_rows, offsets, ids, data, n)
 
     def ande(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
