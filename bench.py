@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched `ands`, 4096 queries x 1 Mi-row CSR database per GPU,
+width 2048 / 40 active ids, EmptyData, uint32 counts[Q][N] (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one query batch: (N > 1 only) RCCL broadcast of the
+packed queries from rank 0, then the size-op call on this rank's row shard.  Inputs are
+resident in HBM before the timed region.  The database is sharded by rows, every rank holds
+1 Mi rows (weak scaling) and counts stay sharded.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WIDTH, ACTIVE = 2048, 40
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def algorithmic_bytes(nq: int, nd: int) -> int:
+    """Read every input once, write every output once: CSR rows are 4*A ids + a 4-byte offset,
+    counts are uint32."""
+    return nd * (4 * ACTIVE + 4) + nq * (4 * ACTIVE + 4) + nq * nd * 4
+
+
+def cpu_baseline(nq: int, nd: int, threads: int):
+    """The reference's own std::vector path (oracle/_ref, built from its headers) on this host's
+    cores over a bounded sample of the same workload; falls back to the C restatement."""
+    import oracle
+    import sdr_amd
+    q = oracle.Batch(*sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE))
+    d = oracle.Batch(*sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE))
+    if oracle.have_reference():
+        impl, kind = oracle.reference(), "reference"
+    else:
+        impl, kind, threads = oracle.port(), "port", 1
+    sec1, chk1 = impl.time_size_op(oracle.AND, q, d, repeats=2, threads=1)
+    one_thread = nq * nd / sec1
+    if threads > 1:
+        sec, chk = impl.time_size_op(oracle.AND, q, d, repeats=3, threads=threads)
+        assert chk == chk1
+    else:
+        sec = sec1
+    return {
+        "value": nq * nd / sec, "unit": "pair-ops/s", "cores": threads, "kind": kind,
+        "sample": f"ands, {nq} queries x {nd} rows, width {WIDTH}/{ACTIVE} active, std::vector rows, "
+                  f"g++ -O2, best of 3; single thread: {one_thread:.3e} pair-ops/s",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="database rows per GPU")
+    ap.add_argument("--op", default="ands", choices=["ands", "ors", "xors", "rms"])
+    ap.add_argument("--algo", default=None, choices=[None, "merge", "bitslice"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import sdr_amd
+    from sdr_amd.shard import HipEngine, ShardedDatabase
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    nq, nd = args.queries, args.rows
+    engine = HipEngine(local_rank)
+
+    # ---- inputs, resident in HBM before the timed region
+    q_off, q_ids, _ = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE)
+    d_off, d_ids, _ = sdr_amd.synth_csr(1, rank * nd, nd, WIDTH, ACTIVE)   # this rank's rows
+    db = ShardedDatabase(engine.pack_host(d_off, d_ids, None, WIDTH), rank * nd, (rank + 1) * nd,
+                         world * nd, WIDTH, engine)
+    packed_q = None
+    if rank == 0:
+        packed_q = (torch.from_numpy(q_off.astype(np.int64).astype(np.int32)).to(dev),
+                    torch.from_numpy(q_ids).to(dev), None)
+    out = torch.empty((nq, nd), dtype=torch.int32, device=dev)
+    queries = db.broadcast_queries(packed_q, src=0)
+
+    def step():
+        q = db.broadcast_queries(packed_q, src=0) if world > 1 else queries
+        getattr(q, args.op)(db.shard, out=out, algo=args.algo)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # device time of the K steps on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    # ---- parity gate on the timed output (outside the timed region)
+    verified = None
+    if not args.no_verify and args.op == "ands":
+        # checksum of checksums: sum of all overlaps == sum over ids of (#queries with id)*(#rows with id)
+        hq = np.bincount(q_ids, minlength=WIDTH).astype(np.int64)
+        hd = np.bincount(d_ids, minlength=WIDTH).astype(np.int64)
+        got = int(out.sum(dtype=torch.int64))
+        verified = got == int((hq * hd).sum())
+        if rank == 0:
+            import oracle
+            rng = np.random.default_rng(0)
+            qi = rng.integers(0, nq, 16)
+            dj = rng.integers(0, nd, 512)
+            want = oracle.port().size_op(oracle.AND, oracle.Batch(*_gather_rows(q_off, q_ids, qi)),
+                                         oracle.Batch(*_gather_rows(d_off, d_ids, dj)))
+            sample = out[torch.from_numpy(qi).to(dev)][:, torch.from_numpy(dj).to(dev)].cpu().numpy()
+            verified = verified and bool(np.array_equal(sample.view(np.uint32), want))
+        if not verified:
+            raise SystemExit("parity check failed: device counts differ from the oracle")
+
+    if rank == 0:
+        pair_ops = world * nq * nd * args.steps
+        ms_per_step = elapsed * 1e3 / args.steps
+        kernel_ms = dev_ms / args.steps
+        ach = algorithmic_bytes(nq, nd) / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("queries") == nq and tj.get("rows") == nd and tj.get("op") == args.op:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "SDR pair-ops/sec (ands, 2048-bit/40-active)",
+            "value": pair_ops / elapsed,
+            "unit": "pair-ops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"batched {args.op}: {nq} queries x {nd} rows per GPU CSR database, "
+                                   f"width {WIDTH}, {ACTIVE} active, EmptyData, uint32 counts[Q][N]",
+                       "queries": nq, "rows_per_gpu": nd, "width": WIDTH, "active": ACTIVE,
+                       "sharding": f"rows x{world}, counts stay sharded"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": algorithmic_bytes(nq, nd)},
+            "parity_checked": verified,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(64, 100_000, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _gather_rows(off, ids, rows):
+    lens = (off[rows + 1] - off[rows]).astype(np.int64)
+    new_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    parts = [ids[int(off[r]):int(off[r + 1])] for r in rows]
+    return new_off, (np.concatenate(parts) if parts else np.zeros(0, np.int32)), None
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,15 @@ int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out
 int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
                           const int32_t* ids, const float* data, void* stream);
 
+/*
+ * Same as sdrb_batch_upload_csr for a CSR pack that already lives in this device's memory
+ * (uint32 row_offsets[n_rows+1]), e.g. a query batch received over RCCL.  The same checks
+ * run in a device kernel; the arrays are copied, so the caller keeps ownership.
+ * Synchronises.
+ */
+int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint32_t* row_offsets,
+                                 const int32_t* ids, const float* data, void* stream);
+
 /* Shape of a batch; any out pointer may be NULL. */
 int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint64_t* nnz,
                     int32_t* width, int* data_kind, uint32_t* max_row_len);

@@ -125,6 +125,31 @@ class SDRBatch:
         check(self._lib.sdrb_batch_info(self._h, None, None, None, None, None, C.byref(mx)))
         self.max_row_len = int(mx.value)
 
+    def upload_device(self, offsets, ids, data=None, *, stream=None) -> None:
+        """Packs a CSR that already lives on this device: ``offsets`` int32 tensor [n_rows+1]
+        (uint32 values), ``ids`` int32 tensor, ``data`` float32 tensor for UnitData batches."""
+        torch = _torch()
+        if offsets.dtype != torch.int32 or ids.dtype != torch.int32 or offsets.dim() != 1 or offsets.numel() < 1:
+            raise ValueError("offsets and ids must be 1-d int32 tensors")
+        if not (offsets.is_contiguous() and ids.is_contiguous()):
+            raise ValueError("offsets and ids must be contiguous")
+        dptr = None
+        if self.data_kind == DATA_UNIT:
+            if data is None or data.dtype != torch.float32 or not data.is_contiguous() or data.numel() != ids.numel():
+                raise ValueError("UnitData batch needs a contiguous float32 payload tensor as long as ids")
+            dptr = data.data_ptr() if data.numel() else None
+        elif data is not None:
+            raise ValueError("EmptyData batch takes no payloads")
+        n_rows = offsets.numel() - 1
+        check(self._lib.sdrb_batch_upload_device_csr(self._h, n_rows, offsets.data_ptr(),
+                                                     ids.data_ptr() if ids.numel() else None, dptr,
+                                                     _stream_handle(self.device, stream)))
+        self.n_rows = n_rows
+        nnz, mx = C.c_uint64(), C.c_uint32()
+        check(self._lib.sdrb_batch_info(self._h, None, None, C.byref(nnz), None, None, C.byref(mx)))
+        self.nnz = int(nnz.value)
+        self.max_row_len = int(mx.value)
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.sdrb_batch_destroy(self._h)

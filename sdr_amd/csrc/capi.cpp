@@ -1,6 +1,7 @@
 // extern "C" boundary of the engine: batch packing into HBM, kernel selection, memory
 // helpers.  No exceptions cross this layer; every entry point returns a status code.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -48,6 +49,40 @@ void free_batch_storage(sdrb_batch* b) {
     b->max_row_len = 0;
     b->min_id = 0;
     b->max_id = -1;
+}
+
+// Device-side validation of a CSR pack that is already in HBM (one thread per row).
+struct PackStats {
+    uint32_t max_len;
+    int32_t min_id;
+    int32_t max_id;
+    uint32_t bad_offsets;   // 1 + first row whose offsets are not monotone / exceed nnz
+    uint32_t bad_order;     // 1 + a row that is not strictly ascending
+    uint32_t bad_payload;   // 1 + an element whose UnitData payload is outside [0,1]
+};
+
+__global__ __launch_bounds__(256) void k_validate_pack(const uint32_t* __restrict__ off,
+                                                       const int32_t* __restrict__ ids,
+                                                       const float* __restrict__ data, uint64_t n_rows,
+                                                       uint32_t nnz, PackStats* __restrict__ st) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t lo = off[r], hi = off[r + 1];
+    if (hi < lo || hi > nnz || (r == 0 && lo != 0)) {
+        atomicMin(&st->bad_offsets, (uint32_t)(r < 0xFFFFFFFEull ? r + 1 : 0xFFFFFFFFu));
+        return;
+    }
+    if (hi == lo) return;
+    atomicMax(&st->max_len, hi - lo);
+    atomicMin(&st->min_id, ids[lo]);
+    atomicMax(&st->max_id, ids[hi - 1]);
+    bool order_ok = true, payload_ok = true;
+    for (uint32_t k = lo; k < hi; ++k) {
+        if (k > lo && ids[k] <= ids[k - 1]) order_ok = false;
+        if (data && !(data[k] >= 0.0f && data[k] <= 1.0f)) payload_ok = false;
+    }
+    if (!order_ok) atomicMin(&st->bad_order, (uint32_t)(r + 1));
+    if (!payload_ok) atomicMin(&st->bad_payload, (uint32_t)(r + 1));
 }
 
 bool valid_op(int op) { return op >= SDRB_OP_AND && op <= SDRB_OP_RM; }
@@ -244,6 +279,78 @@ int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* ro
     batch->max_row_len = max_len;
     batch->min_id = min_id;
     batch->max_id = max_id;
+    return SDRB_OK;
+}
+
+int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint32_t* row_offsets,
+                                 const int32_t* ids, const float* data, void* stream) {
+    if (!batch || !row_offsets) {
+        set_error("sdrb_batch_upload_device_csr: null argument");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (n_rows > 0xFFFFFFFEull) {
+        set_error("too many rows for 32-bit offsets");
+        return SDRB_ERR_OVERFLOW;
+    }
+    const bool unit = batch->data_kind == SDRB_DATA_UNIT;
+    DeviceGuard guard(batch->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", batch->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t nnz = 0;
+    SDRB_HIP(hipMemcpyAsync(&nnz, row_offsets + n_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    if (nnz > 0 && (!ids || (unit && !data))) {
+        set_error("ids (and payloads of a UnitData batch) must not be null");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    PackStats init{0u, INT32_MAX, INT32_MIN, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    PackStats* d_st = static_cast<PackStats*>(workspace(batch->device, 2, sizeof(PackStats)));
+    if (!d_st) return SDRB_ERR_HIP;
+    SDRB_HIP(hipMemcpyAsync(d_st, &init, sizeof init, hipMemcpyHostToDevice, s));
+    if (n_rows) {
+        hipLaunchKernelGGL(k_validate_pack, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, s,
+                           row_offsets, ids, unit ? data : nullptr, n_rows, nnz, d_st);
+        SDRB_HIP(hipGetLastError());
+    }
+    PackStats st;
+    SDRB_HIP(hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    if (st.bad_offsets != 0xFFFFFFFFu) {
+        set_error("row_offsets not monotone (or row_offsets[0] != 0) at row %u", st.bad_offsets - 1);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (st.bad_order != 0xFFFFFFFFu) {
+        set_error("row %u is not strictly ascending", st.bad_order - 1);
+        return SDRB_ERR_NOT_ASCENDING;
+    }
+    if (st.bad_payload != 0xFFFFFFFFu) {
+        set_error("row %u holds a UnitData payload outside [0,1]", st.bad_payload - 1);
+        return SDRB_ERR_PAYLOAD_RANGE;
+    }
+    const bool any = st.max_len > 0;
+    if (batch->width > 0 && any && (st.min_id < 0 || st.max_id >= batch->width)) {
+        set_error("id outside the declared width: ids span [%d, %d], width %d", st.min_id, st.max_id,
+                  batch->width);
+        return SDRB_ERR_ID_RANGE;
+    }
+    free_batch_storage(batch);
+    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
+    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_ids), (size_t)nnz * sizeof(int32_t)));
+    if (nnz && unit) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_data), (size_t)nnz * sizeof(float)));
+    SDRB_HIP(hipMemcpyAsync(batch->d_offsets, row_offsets, (n_rows + 1) * sizeof(uint32_t),
+                            hipMemcpyDeviceToDevice, s));
+    if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (nnz && unit)
+        SDRB_HIP(hipMemcpyAsync(batch->d_data, data, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    batch->n_rows = n_rows;
+    batch->nnz = nnz;
+    batch->max_row_len = st.max_len;
+    batch->min_id = any ? st.min_id : 0;
+    batch->max_id = any ? st.max_id : -1;
     return SDRB_OK;
 }
 

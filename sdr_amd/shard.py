@@ -1,0 +1,178 @@
+"""Row-sharded database across the GPUs of one node, one process per GPU.
+
+Every pair (query, database row) is independent, so the database is split into contiguous
+row ranges, one per rank, each packed as its own CSR with rebased offsets.  The only
+exchange on the data path is the query batch: the source rank broadcasts the packed query
+CSR (header + one int32 buffer; 0.67 MB for 4096 queries of 40 ids) and every rank
+evaluates it against its own shard.  Counts stay sharded -- rank r owns columns
+[row_lo, row_hi) of the global [Q][N] result; all-gathering the full matrix is offered for
+small problems only, since it moves Q*N*4 bytes per GPU over xGMI.
+
+The collectives go through ``torch.distributed`` (backend "nccl" is RCCL on ROCm; "gloo"
+on CPU for tests).  The per-shard computation is delegated to an *engine*; the default
+engine is the HIP library.  Tests inject a CPU engine to exercise the sharding and the
+collectives without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def shard_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced row range of ``rank``: sizes differ by at most one row."""
+    return n_rows * rank // world, n_rows * (rank + 1) // world
+
+
+def slice_csr(off: np.ndarray, ids: np.ndarray, data: Optional[np.ndarray], lo: int, hi: int):
+    """Rows [lo, hi) of a host CSR with offsets rebased to zero."""
+    off = np.asarray(off, dtype=np.uint64)
+    e0, e1 = int(off[lo]), int(off[hi])
+    return (off[lo:hi + 1] - off[lo], ids[e0:e1], None if data is None else data[e0:e1])
+
+
+class HipEngine:
+    """Default engine: batches are :class:`sdr_amd.SDRBatch` objects on ``device``."""
+
+    def __init__(self, device: int):
+        self.device = device
+
+    def torch_device(self):
+        return f"cuda:{self.device}"
+
+    def pack_host(self, off, ids, data, width):
+        from .batch import SDRBatch
+        return SDRBatch.from_csr(off, ids, data, width=width, device=self.device)
+
+    def pack_device(self, off_t, ids_t, data_t, width):
+        from .batch import SDRBatch
+        b = SDRBatch(self.device, width, "unit" if data_t is not None else "empty")
+        b.upload_device(off_t, ids_t, data_t)
+        return b
+
+    def size_op(self, name: str, queries, shard, out=None):
+        return getattr(queries, name)(shard, out=out)
+
+
+class ShardedDatabase:
+    """One rank's view of a row-sharded SDR database."""
+
+    def __init__(self, shard, row_lo: int, row_hi: int, n_rows_total: int, width: int, engine,
+                 group=None):
+        self.shard = shard
+        self.row_lo, self.row_hi, self.n_rows_total = row_lo, row_hi, n_rows_total
+        self.width = width
+        self.engine = engine
+        self.group = group
+
+    # -- construction ---------------------------------------------------------------
+    @classmethod
+    def from_global_csr(cls, off, ids, data, *, width: int, engine, rank: int, world: int, group=None):
+        """Every rank holds (or can generate) the whole host CSR and packs only its rows."""
+        n = len(off) - 1
+        lo, hi = shard_range(n, rank, world)
+        s_off, s_ids, s_data = slice_csr(off, ids, data, lo, hi)
+        return cls(engine.pack_host(s_off, s_ids, s_data, width), lo, hi, n, width, engine, group)
+
+    # -- the exchange step ------------------------------------------------------------
+    def broadcast_queries(self, packed=None, src: int = 0):
+        """Broadcasts a packed query batch from ``src`` and packs it on every rank.
+
+        ``packed`` (needed on ``src`` only) is ``(offsets, ids, data_or_None)`` as torch tensors
+        on the engine's device: int32 offsets [nq+1], int32 ids, float32 payloads.
+        """
+        import torch
+        import torch.distributed as dist
+
+        dev = self.engine.torch_device()
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        if world == 1:
+            off_t, ids_t, data_t = packed
+            return self.engine.pack_device(off_t, ids_t, data_t, self.width)
+        header = torch.zeros(3, dtype=torch.int64, device=dev)
+        if rank == src:
+            off_t, ids_t, data_t = packed
+            header[0], header[1], header[2] = off_t.numel() - 1, ids_t.numel(), int(data_t is not None)
+        dist.broadcast(header, src=src, group=self.group)
+        nq, nnz, has_data = (int(x) for x in header.tolist())
+        total = (nq + 1) + nnz * (2 if has_data else 1)
+        if rank == src:
+            parts = [off_t, ids_t] + ([data_t.view(torch.int32)] if has_data else [])
+            buf = torch.cat(parts)
+        else:
+            buf = torch.empty(total, dtype=torch.int32, device=dev)
+        dist.broadcast(buf, src=src, group=self.group)
+        off_t = buf[: nq + 1]
+        ids_t = buf[nq + 1: nq + 1 + nnz]
+        data_t = buf[nq + 1 + nnz:].view(torch.float32) if has_data else None
+        return self.engine.pack_device(off_t.contiguous(), ids_t.contiguous(),
+                                       None if data_t is None else data_t.contiguous(), self.width)
+
+    # -- per-shard evaluation ----------------------------------------------------------
+    def size_op(self, name: str, queries, out=None):
+        """``name`` in {ands, ors, xors, rms}: counts of ``queries`` x this rank's rows, i.e.
+        columns [row_lo, row_hi) of the global result.  No communication."""
+        return self.engine.size_op(name, queries, self.shard, out=out)
+
+    def gather_counts(self, local_counts):
+        """All-gathers the per-shard count slabs into the full [Q][N] matrix on every rank.
+        Moves Q*N*4 bytes per GPU: meant for small problems and tests, not the timed path."""
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return local_counts
+        nq = local_counts.shape[0]
+        slabs = []
+        for r in range(world):
+            lo, hi = shard_range(self.n_rows_total, r, world)
+            slabs.append(torch.empty((nq, hi - lo), dtype=local_counts.dtype, device=local_counts.device))
+        if _equal_shapes(slabs):
+            dist.all_gather(slabs, local_counts.contiguous(), group=self.group)
+        else:
+            _all_gather_ragged(slabs, local_counts.contiguous(), self.group)
+        return torch.cat(slabs, dim=1)
+
+    def topk(self, local_counts, k: int):
+        """Per query, the k rows with the largest count over the WHOLE database: each rank
+        selects its local top-k, the (count, global row) candidates are all-gathered
+        (Q*k*16 bytes per rank) and merged.  Ties go to the lower row index.  The reference has
+        no top-k; this rule is this engine's own."""
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        n_local = local_counts.shape[1]
+        kk = min(k, n_local)
+        rows = torch.arange(self.row_lo, self.row_lo + n_local, device=local_counts.device, dtype=torch.int64)
+        # sort key: count descending, then row ascending
+        key = local_counts.to(torch.int64) * (self.n_rows_total + 1) + (self.n_rows_total - rows)[None, :]
+        top_key, _ = torch.topk(key, kk, dim=1)
+        if kk < k:
+            pad = torch.full((top_key.shape[0], k - kk), -1, dtype=torch.int64, device=top_key.device)
+            top_key = torch.cat([top_key, pad], dim=1)
+        if world > 1:
+            gathered = [torch.empty_like(top_key) for _ in range(world)]
+            dist.all_gather(gathered, top_key.contiguous(), group=self.group)
+            top_key, _ = torch.topk(torch.cat(gathered, dim=1), k, dim=1)
+        valid = top_key >= 0
+        counts = torch.where(valid, top_key // (self.n_rows_total + 1), torch.zeros_like(top_key))
+        row_ids = torch.where(valid, self.n_rows_total - top_key % (self.n_rows_total + 1),
+                              torch.full_like(top_key, -1))
+        return counts, row_ids
+
+
+def _equal_shapes(tensors) -> bool:
+    return all(t.shape == tensors[0].shape for t in tensors)
+
+
+def _all_gather_ragged(slabs, mine, group):
+    """all_gather for slabs whose widths differ by one row (unbalanced split)."""
+    import torch.distributed as dist
+    for r, slab in enumerate(slabs):
+        if r == dist.get_rank(group):
+            slab.copy_(mine)
+        dist.broadcast(slab, src=r, group=group)
