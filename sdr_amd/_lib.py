@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdr_amd.so")
+# SDR_AMD_LIB selects another build of the engine (kernel tuning experiments)
+LIB_PATH = os.environ.get("SDR_AMD_LIB") or os.path.join(_HERE, "libsdr_amd.so")
 
 OK = 0
 OP_AND, OP_OR, OP_XOR, OP_RM = 0, 1, 2, 3

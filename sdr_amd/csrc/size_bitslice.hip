@@ -15,6 +15,8 @@
 // unpacked four counts at a time into bytes and stored as uint32, one 256-byte coalesced
 // store per wave per A row.  Each row of B is read from HBM once; the output write
 // (4 bytes per pair) is the only large stream, so the kernel is bound by HBM write bandwidth.
+#include <type_traits>
+
 #include "sdrb_internal.h"
 
 namespace sdrb {
@@ -22,20 +24,29 @@ namespace sdrb {
 namespace {
 
 using u64 = unsigned long long;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBlock = 256;
+// tuning constants (overridable at build time for experiments)
+#ifndef SDRB_BS_BLOCK
+#define SDRB_BS_BLOCK 256
+#endif
+#ifndef SDRB_BS_MIN_WAVES
+#define SDRB_BS_MIN_WAVES 3
+#endif
+constexpr int kBlock = SDRB_BS_BLOCK;  // threads per block = rows of B per block
+constexpr int kMinWaves = SDRB_BS_MIN_WAVES;  // waves per SIMD the register allocator must allow
 constexpr int kTileRows = 64;  // rows of A per table tile = bits of one table word
 
 __global__ __launch_bounds__(64) void k_build_table(const uint32_t* __restrict__ a_off,
                                                      const int32_t* __restrict__ a_ids,
-                                                     int32_t width, uint32_t wstride,
+                                                     int32_t width, uint32_t tile_words,
                                                      u64* __restrict__ table,
                                                      uint32_t* __restrict__ a_len) {
     const uint64_t i = blockIdx.x;
     const uint32_t beg = a_off[i];
     const uint32_t len = a_off[i + 1] - beg;
     if (threadIdx.x == 0) a_len[i] = len;
-    u64* tile = table + (i / kTileRows) * (uint64_t)wstride;
+    u64* tile = table + (i / kTileRows) * (uint64_t)tile_words;
     const u64 bit = 1ull << (i % kTileRows);
     for (uint32_t k = threadIdx.x; k < len; k += 64) {
         const int32_t id = a_ids[beg + k];
@@ -50,54 +61,168 @@ constexpr int bits_for(int n) {  // bits needed to hold values 0..n
     return b;
 }
 
-// carry-save adder: (h, l) = a + b + c, bitwise over 64 independent counters
-#define SDRB_CSA(h, l, a, b, c)                    \
-    do {                                           \
-        const u64 u_ = (a) ^ (b);                  \
-        const u64 c_ = (c);                        \
-        (h) = (u_ & c_) | (~u_ & (a));             \
-        (l) = u_ ^ c_;                             \
-    } while (0)
+// full adder over 32 independent 1-bit columns: carry = majority, sum = parity
+__device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b, uint32_t c) {
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+__device__ __forceinline__ void half_add(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b) {
+    carry = a & b;
+    sum = a ^ b;
+}
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int s) {
     return __builtin_amdgcn_alignbit(x, x, (uint32_t)(s & 31));
 }
 
-// NCH  : the lane keeps 8*NCH ids of its row in registers (rows are padded with a sentinel
-//        offset that points at an all-zero table word)
-// MODE : 0 -> out = m;  1 -> out = L - m;  2 -> out = L - 2m   (m = id matches,
-//        L = use_la*|A_i| + use_lb*|B_j|)
-// WCAP : table words per tile held in one LDS buffer (two buffers, double buffered)
-template <int NCH, int MODE, int WCAP>
-__global__ __launch_bounds__(kBlock) void k_size_bitslice(
-    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb,
-    const u64* __restrict__ table, const uint32_t* __restrict__ a_len, uint32_t wstride,
-    uint32_t ntiles, uint32_t tiles_per_block, uint64_t na, uint32_t use_la, uint32_t use_lb,
-    uint32_t* __restrict__ out, uint64_t ld_out) {
+// Adds eight 32-column bit words into the vertical counter P (Harley-Seal step):
+// P[0..2] keep count mod 8, the weight-8 carry ripples into P[3..].
+template <int NPL, bool FIRST>
+__device__ __forceinline__ void add8(uint32_t (&P)[NPL], const uint32_t (&x)[8]) {
+    uint32_t t2a, t2b, t4a, t4b, e8;
+    if constexpr (FIRST) {  // P is all zero
+        half_add(t2a, P[0], x[0], x[1]);
+        csa(t2b, P[0], P[0], x[2], x[3]);
+        half_add(t4a, P[1], t2a, t2b);
+        csa(t2a, P[0], P[0], x[4], x[5]);
+        csa(t2b, P[0], P[0], x[6], x[7]);
+        csa(t4b, P[1], P[1], t2a, t2b);
+        half_add(e8, P[2], t4a, t4b);
+        if constexpr (NPL > 3) P[3] = e8;
+    } else {
+        csa(t2a, P[0], P[0], x[0], x[1]);
+        csa(t2b, P[0], P[0], x[2], x[3]);
+        csa(t4a, P[1], P[1], t2a, t2b);
+        csa(t2a, P[0], P[0], x[4], x[5]);
+        csa(t2b, P[0], P[0], x[6], x[7]);
+        csa(t4b, P[1], P[1], t2a, t2b);
+        csa(e8, P[2], P[2], t4a, t4b);
+#pragma unroll
+        for (int p = 3; p < NPL; ++p) {
+            const uint32_t nc = P[p] & e8;
+            P[p] ^= e8;
+            e8 = nc;
+        }
+    }
+}
+
+template <int PF>
+__device__ __forceinline__ void load_tile(u32x4 (&pf)[PF], const u64* __restrict__ tile, uint32_t tid) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(tile);
+#pragma unroll
+    for (int p = 0; p < PF; ++p) pf[p] = src[tid + p * kBlock];
+}
+
+template <int PF>
+__device__ __forceinline__ void write_tile(const u32x4 (&pf)[PF], u64* buf, uint32_t tid) {
+    u32x4* dst = reinterpret_cast<u32x4*>(buf);
+#pragma unroll
+    for (int p = 0; p < PF; ++p) dst[tid + p * kBlock] = pf[p];
+}
+
+// One tile: gather the row's table words from LDS buffer `buf`, count, unpack, store.
+// `rows_in_tile` < 64 only for the last tile of A; stores to the missing rows are switched
+// off by a zero-sized buffer descriptor, lanes past the last row of B by `nrec`.
+template <int NCH, int MODE>
+__device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[8 * NCH],
+                                          uint32_t rows_in_tile, uint32_t la_vec, uint32_t lbterm,
+                                          char* tile_out, uint64_t row_bytes, uint32_t nrec, uint32_t voff) {
     constexpr int NPL = bits_for(8 * NCH);
     constexpr int SH = MODE == 2 ? 1 : 0;
-    static_assert(NPL + SH <= 8, "counts must fit one byte during unpacking");
-    constexpr int BUF = WCAP + 2;             // words per LDS buffer (sentinel at [wstride])
-    constexpr int PF = WCAP / 2 / kBlock;     // uint4 table loads per thread per tile
+    const char* base = reinterpret_cast<const char*>(buf);
+    uint32_t lo[NPL], hi[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) lo[p] = hi[p] = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        uint32_t xl[8], xh[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u64 w = *reinterpret_cast<const u64*>(base + off[ch * 8 + k]);
+            xl[k] = (uint32_t)w;
+            xh[k] = (uint32_t)(w >> 32);
+        }
+        if (ch == 0) {
+            add8<NPL, true>(lo, xl);
+            add8<NPL, true>(hi, xh);
+        } else {
+            add8<NPL, false>(lo, xl);
+            add8<NPL, false>(hi, xh);
+        }
+    }
+    // unpack one 32-row half at a time: bits r, r+8, r+16, r+24 of plane p -> bit p+SH of
+    // bytes 0..3 of acc[r]; then store in row order of A, advancing the row pointer
+    char* row_ptr = tile_out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const uint32_t w = h ? hi[p] : lo[p];
+                a |= rotr32(w, r - p - SH) & (0x01010101u << (p + SH));
+            }
+            acc[r] = a;
+        }
+#pragma unroll
+        for (int qq = 0; qq < 32; ++qq) {
+            const int q = 32 * h + qq;
+            uint32_t v = (acc[qq & 7] >> (8 * (qq >> 3))) & 0xffu;
+            if constexpr (MODE != 0) {
+                const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)la_vec, q);
+                v = (la + lbterm) - v;
+            }
+            const uint32_t n = (uint32_t)q < rows_in_tile ? nrec : 0u;
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(row_ptr, 0, (int)n, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)voff, 0, 0);
+            row_ptr += row_bytes;
+        }
+    }
+}
+
+// NCH  : the lane keeps 8*NCH ids of its row in registers (shorter rows are padded with a
+//        sentinel offset that points at an all-zero table word)
+// MODE : 0 -> out = m;  1 -> out = L - m;  2 -> out = L - 2m   (m = id matches,
+//        L = use_la*|A_i| + use_lb*|B_j|)
+// WCAP : table words per tile; one tile fills one LDS buffer, two buffers alternate
+template <int NCH, int MODE, int WCAP>
+__global__ __launch_bounds__(kBlock, kMinWaves) void k_size_bitslice(
+    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb,
+    const u64* __restrict__ table, const uint32_t* __restrict__ a_len, uint32_t ntiles,
+    uint32_t tiles_per_block, uint32_t na, uint32_t use_la, uint32_t use_lb,
+    uint32_t* __restrict__ out, uint64_t ld_out) {
+    constexpr int NPL = bits_for(8 * NCH);
+    static_assert(NPL + (MODE == 2 ? 1 : 0) <= 8, "counts must fit one byte during unpacking");
+    constexpr int BUF = WCAP + 2;          // words per LDS buffer (zero sentinel at [WCAP])
+    constexpr int PF = WCAP / 2 / kBlock;  // uint4 table loads per thread per tile
     __shared__ __attribute__((aligned(16))) u64 lds[2 * BUF];
 
     const uint32_t tid = threadIdx.x;
     const uint64_t j0 = (uint64_t)blockIdx.x * kBlock;
     const uint64_t j = j0 + tid;
-    const bool valid = j < nb;
 
-    // this lane's row of B -> LDS byte offsets in registers
+    // this lane's row of B -> LDS byte offsets in registers.  The ids are fetched through a
+    // bounds-checked buffer that starts at the block's first element, so every load can be
+    // issued unconditionally (slots past the row's end are replaced by the sentinel).
     uint32_t beg = 0, lb = 0;
-    if (valid) {
+    if (j < nb) {
         beg = b_off[j];
         lb = b_off[j + 1] - beg;
     }
+    const uint32_t blk_beg = b_off[j0];                                   // uniform
+    const uint64_t blk_last = j0 + kBlock < nb ? j0 + kBlock : nb;
+    const uint32_t blk_end = b_off[blk_last];                             // uniform
+    __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t*>(b_ids) + blk_beg, 0, (int)((blk_end - blk_beg) * 4u), 0x00020000);
+    const uint32_t rel = (beg - blk_beg) * 4u;
     uint32_t off[8 * NCH];
 #pragma unroll
-    for (int k = 0; k < 8 * NCH; ++k) {
-        off[k] = wstride * 8u;
-        if ((uint32_t)k < lb) off[k] = (uint32_t)b_ids[beg + k] * 8u;
-    }
+    for (int k = 0; k < 8 * NCH; ++k)
+        off[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ids_rsrc, (int)(rel + 4u * k), 0, 0);
+#pragma unroll
+    for (int k = 0; k < 8 * NCH; ++k) off[k] = (uint32_t)k < lb ? off[k] * 8u : WCAP * 8u;
     const uint32_t lbterm = use_lb ? lb : 0u;
 
     const uint32_t t0 = blockIdx.y * tiles_per_block;
@@ -105,111 +230,39 @@ __global__ __launch_bounds__(kBlock) void k_size_bitslice(
     if (t0 >= t1) return;
 
     if (tid == 0) {
-        lds[wstride] = 0;
-        lds[BUF + wstride] = 0;
+        lds[WCAP] = 0;
+        lds[BUF + WCAP] = 0;
     }
-
-    uint4 pf[PF];
-    auto load_tile = [&](uint32_t t) {
-        const uint4* src = reinterpret_cast<const uint4*>(table + (uint64_t)t * wstride);
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const uint32_t idx = tid + p * kBlock;
-            if (idx * 2 < wstride) pf[p] = src[idx];
-        }
-    };
-    auto write_tile = [&](int buf) {
-        uint4* dst = reinterpret_cast<uint4*>(lds + buf * BUF);
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const uint32_t idx = tid + p * kBlock;
-            if (idx * 2 < wstride) dst[idx] = pf[p];
-        }
-    };
-
-    load_tile(t0);
-    write_tile(0);
+    u32x4 pf[PF];
+    load_tile(pf, table + (uint64_t)t0 * WCAP, tid);
+    write_tile(pf, lds, tid);
     __syncthreads();
 
-    char* const out_block = reinterpret_cast<char*>(out) + j0 * 4;
+    const uint64_t row_bytes = ld_out * 4;
+    const uint64_t rows_here = nb - j0 < (uint64_t)kBlock ? nb - j0 : (uint64_t)kBlock;
+    const uint32_t nrec = (uint32_t)rows_here * 4;
     const uint32_t voff = tid * 4;
+    char* const out_block = reinterpret_cast<char*>(out) + j0 * 4;
 
-    auto process = [&](uint32_t t, auto buf_tag) {
-        constexpr int BUFSEL = decltype(buf_tag)::value;
+    for (uint32_t t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
-        if (more) load_tile(t + 1);
-
+        if (more) load_tile(pf, table + (uint64_t)(t + 1) * WCAP, tid);
         uint32_t la_vec = 0;
         if constexpr (MODE != 0) {
             if (use_la) la_vec = a_len[(uint64_t)t * kTileRows + (tid & 63)];
         }
-
-        // ---- gather + vertical counters
-        const char* base = reinterpret_cast<const char*>(lds + BUFSEL * BUF);
-        u64 P[NPL];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) P[p] = 0;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            u64 x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const u64*>(base + off[ch * 8 + k]);
-            u64 t2a, t2b, t4a, t4b, e8;
-            SDRB_CSA(t2a, P[0], P[0], x[0], x[1]);
-            SDRB_CSA(t2b, P[0], P[0], x[2], x[3]);
-            SDRB_CSA(t4a, P[1], P[1], t2a, t2b);
-            SDRB_CSA(t2a, P[0], P[0], x[4], x[5]);
-            SDRB_CSA(t2b, P[0], P[0], x[6], x[7]);
-            SDRB_CSA(t4b, P[1], P[1], t2a, t2b);
-            SDRB_CSA(e8, P[2], P[2], t4a, t4b);
-#pragma unroll
-            for (int p = 3; p < NPL; ++p) {  // ripple the weight-8 carry upwards
-                const u64 nc = P[p] & e8;
-                P[p] ^= e8;
-                e8 = nc;
-            }
+        char* tile_out = out_block + (uint64_t)t * kTileRows * row_bytes;
+        const uint32_t rows_left = na - t * kTileRows;
+        const uint32_t rows_in_tile = rows_left < (uint32_t)kTileRows ? rows_left : (uint32_t)kTileRows;
+        // one straight-line body per LDS buffer so that LDS addresses fold into instruction offsets
+        if (((t - t0) & 1) == 0) {
+            tile_body<NCH, MODE>(lds, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff);
+            if (more) write_tile(pf, lds + BUF, tid);
+        } else {
+            tile_body<NCH, MODE>(lds + BUF, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff);
+            if (more) write_tile(pf, lds, tid);
         }
-
-        // ---- unpack 4 counts at a time into bytes, finish the op, store
-        const bool full = ((uint64_t)t + 1) * kTileRows <= na;
-        auto emit = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int p = 0; p < NPL; ++p) {
-                        const uint32_t w = h ? (uint32_t)(P[p] >> 32) : (uint32_t)P[p];
-                        // bits r, r+8, r+16, r+24 of plane p -> bit p+SH of bytes 0..3
-                        acc |= rotr32(w, r - p - SH) & (0x01010101u << (p + SH));
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int q = 32 * h + 8 * c + r;
-                        const uint64_t qi = (uint64_t)t * kTileRows + q;
-                        if (!FULL && qi >= na) continue;
-                        uint32_t v = (acc >> (8 * c)) & 0xffu;
-                        if constexpr (MODE != 0) {
-                            const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)la_vec, q);
-                            v = (la + lbterm) - v;
-                        }
-                        if (valid) *reinterpret_cast<uint32_t*>(out_block + qi * ld_out * 4 + voff) = v;
-                    }
-                }
-            }
-        };
-        if (full) emit(std::true_type{});
-        else emit(std::false_type{});
-
-        if (more) write_tile(BUFSEL ^ 1);
         __syncthreads();
-    };
-
-    for (uint32_t t = t0; t < t1; t += 2) {
-        process(t, std::integral_constant<int, 0>{});
-        if (t + 1 < t1) process(t + 1, std::integral_constant<int, 1>{});
     }
 }
 
@@ -219,9 +272,9 @@ struct Plan {
 };
 
 bool make_plan(const sdrb_batch* a, const sdrb_batch* b, Plan* plan) {
+    (void)a;
     if (b->width <= 0 || b->width > 4096) return false;
     if (b->max_row_len > 64) return false;
-    (void)a;
     plan->nch = b->max_row_len <= 16 ? 2 : b->max_row_len <= 32 ? 4 : b->max_row_len <= 40 ? 5 : 8;
     plan->wcap = b->width <= 2048 ? 2048 : 4096;
     return true;
@@ -232,7 +285,7 @@ struct Args {
     const sdrb_batch* b;
     const u64* table;
     const uint32_t* a_len;
-    uint32_t wstride, ntiles, tiles_per_block, use_la, use_lb;
+    uint32_t ntiles, tiles_per_block, use_la, use_lb;
     dim3 grid;
     uint32_t* out;
     uint64_t ld_out;
@@ -242,9 +295,8 @@ struct Args {
 template <int NCH, int MODE, int WCAP>
 void launch(const Args& g) {
     hipLaunchKernelGGL((k_size_bitslice<NCH, MODE, WCAP>), g.grid, dim3(kBlock), 0, g.stream,
-                       g.b->d_offsets, g.b->d_ids, g.b->n_rows, g.table, g.a_len, g.wstride,
-                       g.ntiles, g.tiles_per_block, g.a->n_rows, g.use_la, g.use_lb, g.out,
-                       g.ld_out);
+                       g.b->d_offsets, g.b->d_ids, g.b->n_rows, g.table, g.a_len, g.ntiles,
+                       g.tiles_per_block, (uint32_t)g.a->n_rows, g.use_la, g.use_lb, g.out, g.ld_out);
 }
 
 template <int NCH, int MODE>
@@ -282,9 +334,8 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     Args g;
     g.a = a;
     g.b = b;
-    g.wstride = ((uint32_t)b->width + 1u) & ~1u;
     g.ntiles = (uint32_t)((a->n_rows + kTileRows - 1) / kTileRows);
-    const size_t table_bytes = (size_t)g.ntiles * g.wstride * sizeof(u64);
+    const size_t table_bytes = (size_t)g.ntiles * plan.wcap * sizeof(u64);
     const size_t len_bytes = (size_t)g.ntiles * kTileRows * sizeof(uint32_t);
     char* ws = static_cast<char*>(workspace(b->device, 0, table_bytes + len_bytes));
     if (!ws) return SDRB_ERR_HIP;
@@ -292,7 +343,7 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     u64* table = reinterpret_cast<u64*>(ws);
     uint32_t* a_len = reinterpret_cast<uint32_t*>(ws + table_bytes);
     hipLaunchKernelGGL(k_build_table, dim3((uint32_t)a->n_rows), dim3(64), 0, stream, a->d_offsets,
-                       a->d_ids, b->width, g.wstride, table, a_len);
+                       a->d_ids, b->width, (uint32_t)plan.wcap, table, a_len);
     SDRB_HIP(hipGetLastError());
     g.table = table;
     g.a_len = a_len;

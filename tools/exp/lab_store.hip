@@ -1,0 +1,82 @@
+// Perf lab (not shipped): which store pattern streams a [Q][N] uint32 matrix fastest on MI355X?
+// Build: hipcc --offload-arch=gfx950 -O3 -o lab_store lab_store.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+constexpr int Q = 4096;
+constexpr size_t N = 1 << 20;
+
+// (a) linear 16B/lane grid-stride fill
+__global__ void k_linear16(uint4* out, size_t n16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) out[i] = make_uint4(1, 2, 3, 4);
+}
+// (b) product pattern: block covers ROWS = blockDim.x*RPL columns, loops over all q; lane stores RPL dwords
+template <int RPL, bool NT>
+__global__ void k_pattern(uint32_t* out, size_t ld, int q0, int q1) {
+    size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL;
+    for (int q = q0 + blockIdx.y; q < q1; q += gridDim.y) {
+        uint32_t* p = out + (size_t)q * ld + j;
+        if constexpr (RPL == 1) { if (NT) __builtin_nontemporal_store((uint32_t)q, p); else *p = q; }
+        else if constexpr (RPL == 2) { uint2 v = make_uint2(q, q); if (NT) { __builtin_nontemporal_store(v.x, p); __builtin_nontemporal_store(v.y, p+1);} else *(uint2*)p = v; }
+        else { typedef uint32_t v4 __attribute__((ext_vector_type(4))); v4 v = {(uint32_t)q,(uint32_t)q,(uint32_t)q,(uint32_t)q}; if (NT) __builtin_nontemporal_store(v, (v4*)p); else *(v4*)p = v; }
+    }
+}
+// (c) q-major tiles like the product: for tile of 64 q: 64 stores back-to-back
+template <int RPL>
+__global__ void k_tiles(uint32_t* out, size_t ld) {
+    size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * RPL;
+    for (int t = 0; t < Q / 64; ++t) {
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            uint32_t* p = out + (size_t)(t * 64 + q) * ld + j;
+            if constexpr (RPL == 1) *p = q + t;
+            else { typedef uint32_t v4 __attribute__((ext_vector_type(4))); v4 v = {(uint32_t)q,(uint32_t)t,(uint32_t)q,(uint32_t)q}; *(v4*)p = v; }
+        }
+    }
+}
+
+template <typename F>
+float timeit(F f, int reps = 5) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    uint32_t* out; size_t bytes = (size_t)Q * N * 4;
+    CK(hipMalloc(&out, bytes));
+    auto report = [&](const char* name, float ms) { printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+    report("hipMemsetAsync", timeit([&] { CK(hipMemsetAsync(out, 1, bytes, 0)); }));
+    for (int g : {2048, 8192, 65536})
+        { char nm[64]; snprintf(nm, 64, "linear16 grid=%d", g); report(nm, timeit([&] { k_linear16<<<g, 256>>>((uint4*)out, bytes / 16); })); }
+    for (int bs : {256, 512, 1024}) {
+        char nm[96];
+        snprintf(nm, 96, "pattern RPL1 block=%d (all q in-block)", bs);
+        report(nm, timeit([&] { k_pattern<1, false><<<dim3(N / bs, 1), bs>>>(out, N, 0, Q); }));
+        snprintf(nm, 96, "pattern RPL1 NT block=%d", bs);
+        report(nm, timeit([&] { k_pattern<1, true><<<dim3(N / bs, 1), bs>>>(out, N, 0, Q); }));
+        snprintf(nm, 96, "pattern RPL4 block=%d", bs);
+        report(nm, timeit([&] { k_pattern<4, false><<<dim3(N / bs / 4, 1), bs>>>(out, N, 0, Q); }));
+        snprintf(nm, 96, "pattern RPL4 NT block=%d", bs);
+        report(nm, timeit([&] { k_pattern<4, true><<<dim3(N / bs / 4, 1), bs>>>(out, N, 0, Q); }));
+        snprintf(nm, 96, "pattern RPL2 block=%d", bs);
+        report(nm, timeit([&] { k_pattern<2, false><<<dim3(N / bs / 2, 1), bs>>>(out, N, 0, Q); }));
+    }
+    report("tiles RPL1 block=256", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }));
+    report("tiles RPL4 block=256", timeit([&] { k_tiles<4><<<N / 1024, 256>>>(out, N); }));
+    report("tiles RPL1 block=1024", timeit([&] { k_tiles<1><<<N / 1024, 1024>>>(out, N); }));
+    // y-split: each block handles a slice of q (more, shorter blocks)
+    report("pattern RPL1 block=256 ysplit=8", timeit([&] { k_pattern<1, false><<<dim3(N / 256, 8), 256>>>(out, N, 0, Q); }));
+    report("pattern RPL4 block=256 ysplit=8", timeit([&] { k_pattern<4, false><<<dim3(N / 1024, 8), 256>>>(out, N, 0, Q); }));
+    return 0;
+}
