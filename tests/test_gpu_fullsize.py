@@ -1,0 +1,96 @@
+"""GPU tests at the benchmark's full size (4096 queries x 1 Mi rows, width 2048, 40 active):
+size-independent properties plus oracle spot checks, since the oracle cannot visit 4.3e9 pairs."""
+import numpy as np
+import pytest
+
+import oracle
+import sdr_amd
+from oracle import Batch
+from sdr_amd import SDRBatch
+
+pytestmark = pytest.mark.gpu
+
+NQ, ND, WIDTH, ACTIVE = 4096, 1 << 20, 2048, 40
+
+
+@pytest.fixture(scope="module")
+def problem():
+    import torch
+    q_csr = sdr_amd.synth_csr(2, 0, NQ, WIDTH, ACTIVE)
+    d_csr = sdr_amd.synth_csr(1, 0, ND, WIDTH, ACTIVE)
+    q = SDRBatch.from_csr(*q_csr, width=WIDTH)
+    d = SDRBatch.from_csr(*d_csr, width=WIDTH)
+    out = torch.empty((NQ, ND), dtype=torch.int32, device="cuda:0")
+    return q_csr, d_csr, q, d, out
+
+
+def gather_rows(csr, rows):
+    off, ids, _ = csr
+    lens = (off[rows + 1] - off[rows]).astype(np.int64)
+    new_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    return Batch(new_off, np.concatenate([ids[int(off[r]):int(off[r + 1])] for r in rows]))
+
+
+def test_full_size_sums_and_samples(problem):
+    import torch
+    q_csr, d_csr, q, d, out = problem
+    hq = np.bincount(q_csr[1], minlength=WIDTH).astype(np.int64)
+    hd = np.bincount(d_csr[1], minlength=WIDTH).astype(np.int64)
+    overlap_total = int((hq * hd).sum())       # sum over ids of (#queries with id) * (#rows with id)
+    len_total = NQ * ND * ACTIVE               # sum over pairs of |q| (= of |d|)
+    rng = np.random.default_rng(1)
+    rows = np.sort(rng.choice(ND, 256, replace=False))
+    sub_d = gather_rows(d_csr, rows)
+    oq = Batch(q_csr[0], q_csr[1])
+    want_sum = {0: overlap_total, 1: 2 * len_total - overlap_total,
+                2: 2 * len_total - 2 * overlap_total, 3: len_total - overlap_total}
+    for op, name in enumerate(("ands", "ors", "xors", "rms")):
+        getattr(q, name)(d, out=out)
+        assert int(out.sum(dtype=torch.int64)) == want_sum[op], name
+        got = out[:, torch.from_numpy(rows).cuda()].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, oracle.port().size_op(op, oq, sub_d)), name
+    # mean overlap ~ A^2 / W: the generator's sanity checksum
+    assert abs(overlap_total / (NQ * ND) - ACTIVE * ACTIVE / WIDTH) < 0.01
+
+
+def test_full_size_merge_kernel_agrees_on_a_slab(problem):
+    # the general merge kernel against the table kernel on 64 queries x 64 Ki rows
+    q_csr, d_csr, q, d, out = problem
+    n = 1 << 16
+    qs = SDRBatch.from_csr(q_csr[0][:65], q_csr[1][: 64 * ACTIVE], width=WIDTH)
+    ds = SDRBatch.from_csr(d_csr[0][: n + 1], d_csr[1][: n * ACTIVE], width=WIDTH)
+    for name in ("ands", "ors", "xors", "rms"):
+        a = getattr(qs, name)(ds, algo="bitslice")
+        b = getattr(qs, name)(ds, algo="merge")
+        assert bool((a == b).all()), name
+
+
+def test_self_overlap_is_row_length(problem):
+    # ands(x, x) on the diagonal is |x|; idempotence of the set algebra
+    q_csr, d_csr, q, d, out = problem
+    res = q.ands(q).cpu().numpy()
+    assert (np.diag(res) == ACTIVE).all()
+    assert (res == res.T).all()
+
+
+def test_element_ops_one_query_against_full_database(problem):
+    # config 3 shape: variable-length outputs over 1 Mi rows; lengths must equal the size ops,
+    # totals must equal the closed forms, and sampled rows must equal the oracle
+    import torch
+    q_csr, d_csr, q, d, out = problem
+    one = SDRBatch.from_csr(q_csr[0][:2], q_csr[1][:ACTIVE], width=WIDTH)
+    oq = Batch(q_csr[0][:2], q_csr[1][:ACTIVE])
+    rng = np.random.default_rng(2)
+    rows = np.sort(rng.choice(ND, 200, replace=False))
+    sub_d = gather_rows(d_csr, rows)
+    for op, (sname, ename) in enumerate((("ands", "ande"), ("ors", "ore"), ("xors", "xore"), ("rms", "rme"))):
+        res = getattr(one, ename)(d)
+        sizes = getattr(one, sname)(d).to(torch.int64).flatten()
+        lens = torch.diff(res.offsets.to(torch.int64))
+        assert bool((lens == sizes).all()), ename
+        assert res.total == int(sizes.sum())
+        off, ids, _ = res.to_host()
+        w_off, w_ids, _ = oracle.port().elem_op(op, oq, sub_d)
+        for k, r in enumerate(rows):
+            got = ids[int(off[r]):int(off[r + 1])]
+            assert np.array_equal(got, w_ids[int(w_off[k]):int(w_off[k + 1])]), (ename, r)

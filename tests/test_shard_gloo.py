@@ -1,0 +1,112 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the row-sharded driver: partitioning, the
+query broadcast, per-shard evaluation, count gathering and the top-k merge.  The per-shard
+computation is done by a CPU engine that this test injects (the oracle); the HIP engine is
+exercised by the GPU tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import util  # noqa: E402
+from sdr_amd.shard import ShardedDatabase, shard_range, slice_csr  # noqa: E402
+
+OPS = {"ands": 0, "ors": 1, "xors": 2, "rms": 3}
+
+
+class OracleEngine:
+    """Test-only engine: batches are oracle.Batch objects, evaluation is the CPU oracle."""
+
+    def torch_device(self):
+        return "cpu"
+
+    def pack_host(self, off, ids, data, width):
+        import oracle
+        return oracle.Batch(off, ids, data)
+
+    def pack_device(self, off_t, ids_t, data_t, width):
+        import oracle
+        return oracle.Batch(off_t.numpy().astype(np.uint64), ids_t.numpy(),
+                            None if data_t is None else data_t.numpy())
+
+    def size_op(self, name, queries, shard, out=None):
+        import oracle
+        return torch.from_numpy(oracle.port().size_op(OPS[name], queries, shard).astype(np.int32))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, with_data, n_rows, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)  # same global database on every rank
+        d_off, d_ids, d_data = util.ragged_rows(rng, n_rows, 300, 40, with_data)
+        q_off, q_ids, q_data = util.ragged_rows(rng, 9, 300, 40, with_data)
+        db = ShardedDatabase.from_global_csr(d_off, d_ids, d_data, width=300, engine=OracleEngine(),
+                                             rank=rank, world=world)
+        assert (db.row_lo, db.row_hi) == shard_range(n_rows, rank, world)
+        packed = None
+        if rank == 0:
+            packed = (torch.from_numpy(q_off.astype(np.int64).astype(np.int32)), torch.from_numpy(q_ids),
+                      None if q_data is None else torch.from_numpy(q_data))
+        queries = db.broadcast_queries(packed, src=0)
+        out = {}
+        for name in OPS:
+            local = db.size_op(name, queries)
+            assert local.shape == (9, db.row_hi - db.row_lo)
+            out[name] = db.gather_counts(local).numpy()
+        counts, rows = db.topk(db.size_op("ands", queries), 5)
+        out["topk_counts"], out["topk_rows"] = counts.numpy(), rows.numpy()
+        if rank == 0:
+            results.update(out)
+        else:  # every rank must hold the same gathered result
+            results["rank1_ands"] = out["ands"]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_data,n_rows", [(False, 101), (True, 64)])
+def test_two_rank_sharded_size_ops(with_data, n_rows):
+    import oracle
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), with_data, n_rows, results), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    d = oracle.Batch(*util.ragged_rows(rng, n_rows, 300, 40, with_data))
+    q = oracle.Batch(*util.ragged_rows(rng, 9, 300, 40, with_data))
+    for name, op in OPS.items():
+        want = oracle.port().size_op(op, q, d)
+        assert np.array_equal(results[name].view(np.uint32), want), name
+    assert np.array_equal(results["rank1_ands"], results["ands"])
+    # top-k: count descending, ties to the lower row index
+    want = oracle.port().size_op(0, q, d).astype(np.int64)
+    for i in range(9):
+        order = sorted(range(n_rows), key=lambda r: (-want[i, r], r))[:5]
+        assert results["topk_rows"][i].tolist() == order
+        assert results["topk_counts"][i].tolist() == [int(want[i, r]) for r in order]
+
+
+def test_slice_csr_rebases_offsets():
+    off = np.array([0, 2, 2, 5, 9], dtype=np.uint64)
+    ids = np.arange(9, dtype=np.int32)
+    s_off, s_ids, s_data = slice_csr(off, ids, None, 1, 3)
+    assert s_off.tolist() == [0, 0, 3] and s_ids.tolist() == [2, 3, 4] and s_data is None
+    parts = [shard_range(10, r, 3) for r in range(3)]
+    assert parts == [(0, 3), (3, 6), (6, 10)]

@@ -40,6 +40,21 @@ __global__ void k_tiles(uint32_t* out, size_t ld) {
     }
 }
 
+// (d) each block owns one contiguous chunk and sweeps it front to back
+template <int W>
+__global__ void k_chunked(uint32_t* out, size_t chunk_elems) {
+    typedef uint32_t vN __attribute__((ext_vector_type(W)));
+    vN* p = (vN*)(out + (size_t)blockIdx.x * chunk_elems);
+    size_t n = chunk_elems / W;
+    vN v; for (int i = 0; i < W; ++i) v[i] = i;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = v;
+}
+template <>
+__global__ void k_chunked<1>(uint32_t* out, size_t chunk_elems) {
+    uint32_t* p = out + (size_t)blockIdx.x * chunk_elems;
+    for (size_t i = threadIdx.x; i < chunk_elems; i += blockDim.x) p[i] = i;
+}
+
 template <typename F>
 float timeit(F f, int reps = 5) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -52,11 +67,34 @@ float timeit(F f, int reps = 5) {
     return best;
 }
 
-int main() {
+int main(int argc, char** argv) {
     uint32_t* out; size_t bytes = (size_t)Q * N * 4;
     CK(hipMalloc(&out, bytes));
+    if (argc > 1) {  // calibration mode for PMC runs: one known-size pattern, three launches
+        for (int i = 0; i < 3; ++i) k_tiles<1><<<N / 256, 256>>>(out, N);
+        CK(hipDeviceSynchronize());
+        printf("calibration: k_tiles<1> wrote %zu bytes per launch\n", bytes);
+        return 0;
+    }
     auto report = [&](const char* name, float ms) { printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
     report("hipMemsetAsync", timeit([&] { CK(hipMemsetAsync(out, 1, bytes, 0)); }));
+    {   // leading-dimension skew: is the 4 MiB power-of-two row stride a DRAM channel/bank problem?
+        uint32_t* out2; CK(hipMalloc(&out2, (size_t)Q * (N + 4096) * 4));
+        for (size_t pad : {0, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096}) {
+            char nm[64]; snprintf(nm, 64, "tiles RPL1 block=256 ld=N+%zu", pad);
+            report(nm, timeit([&] { k_tiles<1><<<N / 256, 256>>>(out2, N + pad); }));
+        }
+        for (size_t pad : {0, 64, 1024}) {
+            char nm[64]; snprintf(nm, 64, "pattern RPL4 block=256 ld=N+%zu", pad);
+            report(nm, timeit([&] { k_pattern<4, false><<<dim3(N / 1024, 1), 256>>>(out2, N + pad, 0, Q); }));
+        }
+        CK(hipFree(out2));
+    }
+    for (int g : {256, 512, 1024, 2048, 4096, 16384, 65536}) for (int bs : {256, 1024}) {
+        char nm[64]; size_t chunk = (size_t)Q * N / g;
+        snprintf(nm, 64, "chunked x4 grid=%d block=%d", g, bs); report(nm, timeit([&] { k_chunked<4><<<g, bs>>>(out, chunk); }));
+        snprintf(nm, 64, "chunked x1 grid=%d block=%d", g, bs); report(nm, timeit([&] { k_chunked<1><<<g, bs>>>(out, chunk); }));
+    }
     for (int g : {2048, 8192, 65536})
         { char nm[64]; snprintf(nm, 64, "linear16 grid=%d", g); report(nm, timeit([&] { k_linear16<<<g, 256>>>((uint4*)out, bytes / 16); })); }
     for (int bs : {256, 512, 1024}) {
