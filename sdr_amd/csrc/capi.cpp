@@ -413,8 +413,10 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (can_bitslice && !(flags & SDRB_FLAG_FORCE_MERGE))
-        return launch_size_bitslice(a, b, op, swap, out, ld_out, s);
+    if (!(flags & SDRB_FLAG_FORCE_MERGE)) {
+        if (can_bitslice) return launch_size_bitslice(a, b, op, swap, out, ld_out, s);
+        if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
+    }
     return launch_size_merge(a, b, op, swap, out, ld_out, s);
 }
 
@@ -480,8 +482,13 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
         set_error("hipSetDevice(%d) failed", b->device);
         return SDRB_ERR_HIP;
     }
-    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids, out_data,
-                            static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!(flags & SDRB_FLAG_FORCE_MERGE)) {
+        if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
+        if (unit_table_fill_applicable(a, b, op, swap))
+            return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
+    }
+    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids, out_data, s);
 }
 
 int sdrb_malloc(int device, size_t bytes, void** ptr) {

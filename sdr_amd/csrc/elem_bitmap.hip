@@ -1,0 +1,204 @@
+// Dense-bitset fill kernel for the element ops whose result carries ids only (`this` side
+// EmptyData): ande/ore/xore/rme become AND / OR / XOR / AND-NOT of two bitsets.
+//
+// The reference produces these results with the merges andv/orv (SDR.hpp:958-997, 1099-1150)
+// and pushes ids in ascending order (SDR.hpp:1015-1021, 1207-1217, 1332-1344, 1540-1560); with
+// EmptyData every match is kept by ande/ore and dropped by xore/rme (EmptyData.hpp:29-37).
+// A sorted id set over a declared width W is the same thing as a W-bit set, so here one wave
+// owns one pair at a time: the 64 lanes hold the W bits of row i of A (precomputed once per
+// call, 256 B per row at W = 2048) and of row j of B (scattered from its CSR ids through a
+// per-wave LDS word array), combine them with one bitwise instruction, turn per-lane popcounts
+// into write positions with a wave scan, and enumerate their set bits in ascending id order
+// into the pair's slot of the output CSR.  Reads are coalesced (a row's ids are contiguous)
+// and every wave writes one contiguous run.
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+template <typename WORD>
+__global__ __launch_bounds__(64) void k_build_bitsets(const uint32_t* __restrict__ a_off,
+                                                      const int32_t* __restrict__ a_ids,
+                                                      WORD* __restrict__ bits) {
+    constexpr int BITS = sizeof(WORD) * 8;
+    const uint64_t i = blockIdx.x;
+    const uint32_t beg = a_off[i], len = a_off[i + 1] - beg;
+    WORD* row = bits + i * 64;
+    for (uint32_t k = threadIdx.x; k < len; k += 64) {
+        const uint32_t id = (uint32_t)a_ids[beg + k];  // host checked 0 <= id < 64*BITS
+        atomicOr(&row[id / BITS], (WORD)1 << (id % BITS));
+    }
+}
+
+__device__ __forceinline__ uint32_t popc(uint32_t x) { return __builtin_popcount(x); }
+__device__ __forceinline__ uint32_t popc(unsigned long long x) { return __builtin_popcountll(x); }
+__device__ __forceinline__ uint32_t lowbit(uint32_t x) { return __builtin_ctz(x); }
+__device__ __forceinline__ uint32_t lowbit(unsigned long long x) { return __builtin_ctzll(x); }
+
+constexpr int kStage = 256;   // ids a wave can stage in LDS for one coalesced copy-out
+constexpr int kQueryChunk = 16;  // rows of A a block visits per row of B (grid.y splits A)
+
+template <typename T>
+__device__ __forceinline__ void lds_store(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <typename T>
+__device__ __forceinline__ T lds_load(T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// The LDS executes one wave's operations in program order, so lanes of a wave exchange data
+// through it without a hardware barrier; wavefront-scope atomics and fences only keep the
+// compiler from treating a word as private to its lane.
+template <typename WORD, int OP, bool SWAP>
+__global__ __launch_bounds__(kBlock) void k_elem_bitmap(
+    const WORD* __restrict__ a_bits, uint32_t na, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, uint32_t nb, const uint32_t* __restrict__ out_off,
+    int32_t* __restrict__ out_ids, uint32_t rows_per_wave) {
+    constexpr int BITS = sizeof(WORD) * 8;
+    __shared__ WORD lds_bits[kWaves][64];
+    __shared__ int32_t lds_stage[kWaves][kStage];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * rows_per_wave;
+    const uint64_t j_end = j_begin + rows_per_wave < nb ? j_begin + rows_per_wave : nb;
+    const uint32_t i_begin = blockIdx.y * kQueryChunk;
+    const uint32_t i_end = i_begin + kQueryChunk < na ? i_begin + kQueryChunk : na;
+
+    for (uint64_t j = j_begin; j < j_end; ++j) {
+        // row j of B as a bitset: zero the wave's words, OR the ids in, read my word back
+        const uint32_t beg = b_off[j], len = b_off[j + 1] - beg;
+        lds_store(&lds_bits[wave][lane], (WORD)0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (uint32_t k = lane; k < len; k += 64) {
+            const uint32_t id = (uint32_t)b_ids[beg + k];
+            __hip_atomic_fetch_or(&lds_bits[wave][id / BITS], (WORD)1 << (id % BITS), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const WORD rbits = lds_load(&lds_bits[wave][lane]);
+
+        for (uint32_t i = i_begin; i < i_end; ++i) {
+            const WORD qbits = a_bits[(uint64_t)i * 64 + lane];
+            const WORD self = SWAP ? rbits : qbits, arg = SWAP ? qbits : rbits;
+            WORD res;
+            if constexpr (OP == SDRB_OP_AND) res = self & arg;
+            else if constexpr (OP == SDRB_OP_OR) res = self | arg;
+            else if constexpr (OP == SDRB_OP_XOR) res = self ^ arg;
+            else res = self & ~arg;
+            // wave scan of the per-lane popcounts -> position of each lane's first id
+            const uint32_t cnt = popc(res);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            const uint32_t total = __shfl(incl, 63, 64);
+            if (total == 0) continue;
+            const uint32_t base = out_off[(uint64_t)i * nb + j];
+            uint32_t pos = incl - cnt;
+            if (total <= (uint32_t)kStage) {
+                // enumerate the set bits into LDS, then copy out with fully coalesced stores
+                while (res) {
+                    lds_store(&lds_stage[wave][pos++], (int32_t)(lane * BITS + lowbit(res)));
+                    res &= res - 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (uint32_t t = lane; t < total; t += 64) out_ids[base + t] = lds_load(&lds_stage[wave][t]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            } else {
+                pos += base;
+                while (res) {
+                    out_ids[pos++] = (int32_t)(lane * BITS + lowbit(res));
+                    res &= res - 1;
+                }
+            }
+        }
+    }
+}
+
+struct Args {
+    const void* a_bits;
+    const sdrb_batch* a;
+    const sdrb_batch* b;
+    const uint32_t* out_off;
+    int32_t* out_ids;
+    uint32_t rows_per_wave;
+    dim3 grid;
+    hipStream_t stream;
+};
+
+template <typename WORD, int OP, bool SWAP>
+void launch(const Args& g) {
+    hipLaunchKernelGGL((k_elem_bitmap<WORD, OP, SWAP>), g.grid, dim3(kBlock), 0, g.stream,
+                       static_cast<const WORD*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
+                       g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
+}
+
+template <typename WORD, int OP>
+void launch_swap(const Args& g, bool swap) {
+    if (swap) launch<WORD, OP, true>(g);
+    else launch<WORD, OP, false>(g);
+}
+
+template <typename WORD>
+int run(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_off,
+        int32_t* out_ids, hipStream_t stream) {
+    const size_t bytes = (size_t)a->n_rows * 64 * sizeof(WORD);
+    WORD* bits = static_cast<WORD*>(workspace(b->device, 3, bytes));
+    if (!bits) return SDRB_ERR_HIP;
+    SDRB_HIP(hipMemsetAsync(bits, 0, bytes, stream));
+    hipLaunchKernelGGL(k_build_bitsets<WORD>, dim3((uint32_t)a->n_rows), dim3(64), 0, stream,
+                       a->d_offsets, a->d_ids, bits);
+    SDRB_HIP(hipGetLastError());
+
+    Args g;
+    g.a_bits = bits;
+    g.a = a;
+    g.b = b;
+    g.out_off = out_off;
+    g.out_ids = out_ids;
+    g.stream = stream;
+    // enough waves to fill the chip, few enough that each amortises its setup
+    const uint64_t nb = b->n_rows;
+    uint32_t rpw = 16;
+    const uint64_t ychunks = (a->n_rows + kQueryChunk - 1) / kQueryChunk;
+    while (rpw > 1 && (nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves) * ychunks < 4096) rpw >>= 1;
+    g.rows_per_wave = rpw;
+    const uint32_t gx = (uint32_t)((nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves));
+    const uint32_t gy = (uint32_t)((a->n_rows + kQueryChunk - 1) / kQueryChunk);
+    g.grid = dim3(gx, gy);
+    switch (op) {
+    case SDRB_OP_AND: launch_swap<WORD, SDRB_OP_AND>(g, swap); break;
+    case SDRB_OP_OR: launch_swap<WORD, SDRB_OP_OR>(g, swap); break;
+    case SDRB_OP_XOR: launch_swap<WORD, SDRB_OP_XOR>(g, swap); break;
+    case SDRB_OP_RM: launch_swap<WORD, SDRB_OP_RM>(g, swap); break;
+    default: set_error("unknown op %d", op); return SDRB_ERR_INVALID_ARG;
+    }
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+}  // namespace
+
+bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap) {
+    const sdrb_batch* self = swap ? b : a;
+    if (self->data_kind != SDRB_DATA_EMPTY) return false;       // results would carry payloads
+    if (b->width <= 0 || b->width > 4096) return false;
+    if (a->n_rows > 65535ull * kQueryChunk) return false;        // grid.y limit
+    // every id of A must be representable in the bitset too (A-only ids appear in ore/xore)
+    if (a->nnz && (a->min_id < 0 || a->max_id >= b->width)) return false;
+    return true;
+}
+
+int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                       const uint32_t* out_offsets, int32_t* out_ids, hipStream_t stream) {
+    if (b->width <= 2048) return run<uint32_t>(a, b, op, swap, out_offsets, out_ids, stream);
+    return run<unsigned long long>(a, b, op, swap, out_offsets, out_ids, stream);
+}
+
+}  // namespace sdrb

@@ -27,7 +27,7 @@ namespace sdrb {
 void set_error(const char* fmt, ...);
 
 // Per-device scratch that grows on demand and lives until process exit.
-// slot 0: query bit-table; slot 1: scan block sums.
+// slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A.
 void* workspace(int device, int slot, size_t bytes);
 
 #define SDRB_HIP(call)                                                                   \
@@ -62,5 +62,21 @@ int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                      const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
                      hipStream_t stream);
+
+// elem_bitmap.hip ------------------------------------------------------------------
+// Dense-bitset fill for id-only results (`this` side EmptyData, declared width <= 4096).
+bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);
+int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                       const uint32_t* out_offsets, int32_t* out_ids, hipStream_t stream);
+
+// unit_table.hip --------------------------------------------------------------------
+// Wave-per-row kernels with an LDS position table of one row of A (declared width <= 32768).
+bool unit_table_applicable(const sdrb_batch* a, const sdrb_batch* b);
+bool unit_table_fill_applicable(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap);
+int launch_size_unit_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                           uint32_t* out, uint64_t ld_out, hipStream_t stream);
+int launch_elem_unit_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                           const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
+                           hipStream_t stream);
 
 }  // namespace sdrb

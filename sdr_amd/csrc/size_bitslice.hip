@@ -188,7 +188,7 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
 //        L = use_la*|A_i| + use_lb*|B_j|)
 // WCAP : table words per tile; one tile fills one LDS buffer, two buffers alternate
 template <int NCH, int MODE, int WCAP>
-__global__ __launch_bounds__(kBlock, kMinWaves) void k_size_bitslice(
+__global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_bitslice(
     const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb,
     const u64* __restrict__ table, const uint32_t* __restrict__ a_len, uint32_t ntiles,
     uint32_t tiles_per_block, uint32_t na, uint32_t use_la, uint32_t use_lb,

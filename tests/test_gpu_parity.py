@@ -210,3 +210,58 @@ def test_readme_examples_on_device():
     assert q.ande(q).total == 0 and int(q.ands(q)[0, 0]) == 0  # README.md:120-123
     off, ids, data = u.ande(SDRBatch.from_rows([[0]])).to_host()  # README.md:127-128
     assert ids.tolist() == [0] and data.tolist() == [0.5]
+
+
+@pytest.mark.parametrize("width,max_len", [(2048, 40), (4096, 100), (100, 100), (33, 20)])
+@pytest.mark.parametrize("au", [False, True])
+def test_bitset_element_kernel_vs_oracle(width, max_len, au):
+    # `this` EmptyData => results carry ids only => dense-bitset fill; the general merge fill must agree
+    rng = np.random.default_rng(width + max_len + au)
+    t = Batch(*util.ragged_rows(rng, 19, width, max_len))
+    a = Batch(*util.ragged_rows(rng, 777, width, max_len, au))
+    dt, da = dev(t, width), dev(a, width)
+    for op in range(4):
+        want = oracle.port().elem_op(op, t, a)
+        assert_elems_equal(gpu_elems(op, dt, da), want)
+        assert_elems_equal(gpu_elems(op, dt, da, algo="merge"), want)
+    # swapped roles: this = rows of the second batch
+    b2 = Batch(*util.ragged_rows(rng, 300, width, max_len))
+    db2 = dev(b2, width)
+    for op in range(4):
+        off, ids, data = gpu_elems(op, dt, db2, swap=True)
+        w_off, w_ids, w_data = oracle.port().elem_op(op, b2, t)
+        assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, b2.n),
+                              util.pair_digests(w_off, w_ids, w_data).reshape(b2.n, t.n).T)
+
+
+def test_bitset_element_kernel_not_used_when_a_exceeds_width():
+    rng = np.random.default_rng(77)
+    t = Batch(*util.ragged_rows(rng, 5, 600, 30))          # ids up to 599
+    a = Batch(*util.ragged_rows(rng, 100, 256, 30))        # declared width 256
+    dt, da = dev(t), dev(a, 256)
+    for op in range(4):
+        assert_elems_equal(gpu_elems(op, dt, da), oracle.port().elem_op(op, t, a))
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("width,len_a,len_b", [(16384, 400, 400), (5000, 70, 130), (32768, 30, 500), (257, 200, 257)])
+def test_table_kernels_with_declared_width_vs_oracle(name, width, len_a, len_b):
+    # payload-dependent ops (and long rows / wide id spaces) go through the wave-per-row table
+    # kernels; the general merge kernels and the oracle must agree bit for bit
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(width + len_a + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, 21, width, len_a, tu))
+    a = Batch(*util.ragged_rows(rng, 150, width, len_b, au))
+    dt, da = dev(t, width), dev(a, width)
+    for op in range(4):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(gpu_sizes(op, dt, da), want)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="merge"), want)
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T)
+        w = oracle.port().elem_op(op, t, a)
+        assert_elems_equal(gpu_elems(op, dt, da), w)
+        assert_elems_equal(gpu_elems(op, dt, da, algo="merge"), w)
+        off, ids, data = gpu_elems(op, dt, da, swap=True)
+        w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
+        assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
+                              util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
