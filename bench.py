@@ -68,7 +68,7 @@ def main() -> None:
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--rows", type=int, default=1 << 20, help="database rows per GPU")
     ap.add_argument("--op", default="ands", choices=["ands", "ors", "xors", "rms"])
-    ap.add_argument("--algo", default=None, choices=[None, "merge", "bitslice"])
+    ap.add_argument("--algo", default=None, choices=[None, "merge", "bitslice", "popcount"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()

@@ -55,6 +55,7 @@ extern "C" {
 #define SDRB_FLAG_SWAP 1u           /* result(i,j) = B_j.op(A_i) instead of A_i.op(B_j) */
 #define SDRB_FLAG_FORCE_MERGE 2u    /* always use the general per-pair merge kernels */
 #define SDRB_FLAG_FORCE_BITSLICE 4u /* size ops: fail with UNSUPPORTED unless the bit-sliced kernel applies */
+#define SDRB_FLAG_FORCE_POPCOUNT 8u /* size ops: fail with UNSUPPORTED unless the dense-bitset popcount kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;
 

@@ -16,7 +16,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_SWAP,
+from ._lib import (DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_POPCOUNT, FLAG_SWAP,
                    OP_AND, OP_OR, OP_RM, OP_XOR, check)
 
 _KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT}
@@ -171,8 +171,10 @@ class SDRBatch:
             f |= FLAG_FORCE_MERGE
         elif algo == "bitslice":
             f |= FLAG_FORCE_BITSLICE
+        elif algo == "popcount":
+            f |= FLAG_FORCE_POPCOUNT
         elif algo is not None:
-            raise ValueError("algo must be None, 'merge' or 'bitslice'")
+            raise ValueError("algo must be None, 'merge', 'bitslice' or 'popcount'")
         return f
 
     def _size_op(self, op: int, other: "SDRBatch", swap: bool, out, stream, algo):

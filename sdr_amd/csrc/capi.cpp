@@ -41,6 +41,8 @@ void free_batch_storage(sdrb_batch* b) {
     if (b->d_offsets) (void)hipFree(b->d_offsets);
     if (b->d_ids) (void)hipFree(b->d_ids);
     if (b->d_data) (void)hipFree(b->d_data);
+    if (b->d_bitplanes) (void)hipFree(b->d_bitplanes);
+    b->d_bitplanes = nullptr;
     b->d_offsets = nullptr;
     b->d_ids = nullptr;
     b->d_data = nullptr;
@@ -413,8 +415,18 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & SDRB_FLAG_FORCE_POPCOUNT) {
+        if (!id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
+            set_error("popcount kernel requested but not applicable to these batches/op");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_size_popcount(a, b, op, swap, out, ld_out, s);
+    }
     if (!(flags & SDRB_FLAG_FORCE_MERGE)) {
         if (can_bitslice) return launch_size_bitslice(a, b, op, swap, out, ld_out, s);
+        // rows too long for the bit-sliced kernel: the popcount kernel's cost does not depend on row length
+        if (id_only(a, b, op, swap) && popcount_applicable(a, b))
+            return launch_size_popcount(a, b, op, swap, out, ld_out, s);
         if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
     }
     return launch_size_merge(a, b, op, swap, out, ld_out, s);

@@ -20,6 +20,7 @@ struct sdrb_batch {
     uint32_t* d_offsets = nullptr;    // [n_rows + 1]
     int32_t* d_ids = nullptr;         // [nnz]
     float* d_data = nullptr;          // [nnz] or null
+    uint32_t* d_bitplanes = nullptr;  // derived, built on demand: word w of row j at [w*n_rows + j]
 };
 
 namespace sdrb {
@@ -68,6 +69,12 @@ int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
 bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);
 int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                        const uint32_t* out_offsets, int32_t* out_ids, hipStream_t stream);
+
+// size_popcount.hip ------------------------------------------------------------------
+// Dense-bitset popcount size ops (id-only results, declared width <= 2048).
+bool popcount_applicable(const sdrb_batch* a, const sdrb_batch* b);
+int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                         uint32_t* out, uint64_t ld_out, hipStream_t stream);
 
 // unit_table.hip --------------------------------------------------------------------
 // Wave-per-row kernels with an LDS position table of one row of A (declared width <= 32768).

@@ -265,3 +265,24 @@ def test_table_kernels_with_declared_width_vs_oracle(name, width, len_a, len_b):
         w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
         assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
                               util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
+
+
+@pytest.mark.parametrize("width,max_len,nq,nd", [(2048, 40, 70, 700), (2048, 2048, 9, 300), (1000, 600, 33, 513),
+                                                 (300, 300, 1, 257), (64, 64, 130, 100)])
+@pytest.mark.parametrize("au", [False, True])
+def test_popcount_kernel_vs_oracle(width, max_len, nq, nd, au):
+    # dense-bitset popcount size ops: any row density, id-only results
+    rng = np.random.default_rng(width + max_len + nq)
+    t = Batch(*util.ragged_rows(rng, nq, width + 50, min(max_len, width), lo=-20))   # some ids outside B's width
+    a = Batch(*util.ragged_rows(rng, nd, width, max_len, au))
+    dt, da = dev(t), dev(a, width)
+    for op in range(4):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="popcount"), want)
+        assert np.array_equal(gpu_sizes(op, dt, da), want)           # auto: bit-sliced or popcount
+    want = oracle.port().size_op(RM, a, t).T
+    if not au:
+        assert np.array_equal(gpu_sizes(RM, dt, da, swap=True, algo="popcount"), want)
+    else:   # `this` would be UnitData: payload-dependent, popcount must refuse
+        with pytest.raises(sdr_amd.SdrbError):
+            gpu_sizes(RM, dt, da, swap=True, algo="popcount")
