@@ -71,6 +71,8 @@ def main() -> None:
     ap.add_argument("--algo", default=None, choices=[None, "merge", "bitslice", "popcount"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise RCCL and broadcast the queries every step even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -86,8 +88,12 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+    use_dist = world > 1 or args.force_collectives
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     nq, nd = args.queries, args.rows
     engine = HipEngine(local_rank)
@@ -97,20 +103,26 @@ def main() -> None:
     d_off, d_ids, _ = sdr_amd.synth_csr(1, rank * nd, nd, WIDTH, ACTIVE)   # this rank's rows
     db = ShardedDatabase(engine.pack_host(d_off, d_ids, None, WIDTH), rank * nd, (rank + 1) * nd,
                          world * nd, WIDTH, engine)
-    packed_q = None
-    if rank == 0:
-        packed_q = (torch.from_numpy(q_off.astype(np.int64).astype(np.int32)).to(dev),
-                    torch.from_numpy(q_ids).to(dev), None)
+    # the query batch in wire form; its plan (shape + id statistics) is known on every rank
+    from sdr_amd.shard import PackedQueries
+    packed_q = PackedQueries.from_host_csr(q_off, q_ids, None, width=WIDTH, engine=engine)
+    plan = packed_q.plan
+    recv = torch.empty(plan.words, dtype=torch.int32, device=dev) if rank != 0 else None
+    if rank != 0:
+        packed_q = None
     out = torch.empty((nq, nd), dtype=torch.int32, device=dev)
-    queries = db.broadcast_queries(packed_q, src=0)
+    state = {"queries": db.broadcast_packed(packed_q, plan, src=0, force_collective=args.force_collectives, recv=recv)}
 
     def step():
-        q = db.broadcast_queries(packed_q, src=0) if world > 1 else queries
-        getattr(q, args.op)(db.shard, out=out, algo=args.algo)
+        # N > 1: one RCCL broadcast of the packed queries, adopted in place, then the kernel
+        if use_dist:
+            state["queries"] = db.broadcast_packed(packed_q, plan, src=0, force_collective=args.force_collectives,
+                                                   recv=recv, into=state["queries"])
+        getattr(state["queries"], args.op)(db.shard, out=out, algo=args.algo)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -127,7 +139,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # device time of the K steps on the launch stream
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
@@ -190,7 +202,7 @@ def main() -> None:
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(64, 100_000, threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -90,15 +90,31 @@ int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* ro
 /*
  * Same as sdrb_batch_upload_csr for a CSR pack that already lives in this device's memory
  * (uint32 row_offsets[n_rows+1]), e.g. a query batch received over RCCL.  The same checks
- * run in a device kernel; the arrays are copied, so the caller keeps ownership.
- * Synchronises.
+ * run in a device kernel (one stream synchronisation to read its verdict); the arrays are then
+ * copied on `stream`, so the caller keeps ownership but must leave them unchanged until the
+ * stream has passed this call.  Later calls on the same stream see the new content.
  */
 int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint32_t* row_offsets,
                                  const int32_t* ids, const float* data, void* stream);
 
+/*
+ * Makes the batch a VIEW of a CSR pack in this device's memory: nothing is copied, checked or
+ * synchronised.  The caller vouches that the arrays hold a batch that has already been
+ * validated (e.g. the arrays of another rank's uploaded batch, received over RCCL together with
+ * that batch's statistics) and keeps them alive and unchanged while the batch is in use.
+ * max_row_len, min_id and max_id are the values sdrb_batch_info / sdrb_batch_id_span report
+ * for the validated original.
+ */
+int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz, const uint32_t* row_offsets,
+                                const int32_t* ids, const float* data, uint32_t max_row_len,
+                                int32_t min_id, int32_t max_id);
+
 /* Shape of a batch; any out pointer may be NULL. */
 int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint64_t* nnz,
                     int32_t* width, int* data_kind, uint32_t* max_row_len);
+
+/* Smallest and largest id over all rows (min_id > max_id for a batch without elements). */
+int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id);
 
 /* Device pointers of the packed CSR (read-only views, valid until the next upload/destroy). */
 int sdrb_batch_device_ptrs(const sdrb_batch* batch, const uint32_t** row_offsets,

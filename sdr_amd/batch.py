@@ -150,6 +150,31 @@ class SDRBatch:
         self.nnz = int(nnz.value)
         self.max_row_len = int(mx.value)
 
+    def adopt_device(self, offsets, ids, data=None, *, max_row_len: int, min_id: int, max_id: int) -> None:
+        """Makes this batch a zero-copy VIEW of CSR tensors on its device that are known to hold
+        an already validated batch (``max_row_len``/``min_id``/``max_id`` are that batch's
+        statistics, see :meth:`stats`).  Nothing is checked, copied or synchronised; the tensors
+        are kept referenced here so they outlive the view."""
+        torch = _torch()
+        if offsets.dtype != torch.int32 or ids.dtype != torch.int32 or not offsets.is_contiguous() \
+                or not ids.is_contiguous():
+            raise ValueError("offsets and ids must be contiguous int32 tensors")
+        if (self.data_kind == DATA_UNIT) != (data is not None):
+            raise ValueError("payload tensor must be given exactly for UnitData batches")
+        n_rows, nnz = offsets.numel() - 1, ids.numel()
+        check(self._lib.sdrb_batch_adopt_device_csr(
+            self._h, n_rows, nnz, offsets.data_ptr(), ids.data_ptr() if nnz else None,
+            data.data_ptr() if (data is not None and nnz) else None, max_row_len, min_id, max_id))
+        self._views = (offsets, ids, data)
+        self.n_rows, self.nnz, self.max_row_len = n_rows, nnz, int(max_row_len)
+
+    def stats(self) -> dict:
+        """Shape and id statistics of the uploaded batch (what a zero-copy view needs)."""
+        lo, hi = C.c_int32(), C.c_int32()
+        check(self._lib.sdrb_batch_id_span(self._h, C.byref(lo), C.byref(hi)))
+        return dict(n_rows=self.n_rows, nnz=self.nnz, max_row_len=self.max_row_len,
+                    min_id=int(lo.value), max_id=int(hi.value), has_data=self.data_kind == DATA_UNIT)
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.sdrb_batch_destroy(self._h)

@@ -38,19 +38,42 @@ std::mutex g_ws_mutex;
 std::map<std::pair<int, int>, Scratch> g_ws;
 
 void free_batch_storage(sdrb_batch* b) {
-    if (b->d_offsets) (void)hipFree(b->d_offsets);
-    if (b->d_ids) (void)hipFree(b->d_ids);
-    if (b->d_data) (void)hipFree(b->d_data);
+    if (b->owns_storage) {
+        if (b->d_offsets) (void)hipFree(b->d_offsets);
+        if (b->d_ids) (void)hipFree(b->d_ids);
+        if (b->d_data) (void)hipFree(b->d_data);
+    }
+    b->owns_storage = true;
     if (b->d_bitplanes) (void)hipFree(b->d_bitplanes);
     b->d_bitplanes = nullptr;
     b->d_offsets = nullptr;
     b->d_ids = nullptr;
     b->d_data = nullptr;
+    b->cap_rows = b->cap_nnz = 0;
     b->n_rows = 0;
     b->nnz = 0;
     b->max_row_len = 0;
     b->min_id = 0;
     b->max_id = -1;
+}
+
+// Makes room for n_rows rows / nnz elements, keeping the current allocation when it is large
+// enough (repeated uploads of similar batches, e.g. one query batch per step, then cost no
+// hipMalloc/hipFree).  Derived data of the previous content is dropped.
+int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
+    const bool unit = b->data_kind == SDRB_DATA_UNIT;
+    if (b->d_bitplanes) {
+        (void)hipFree(b->d_bitplanes);
+        b->d_bitplanes = nullptr;
+    }
+    if (b->owns_storage && b->d_offsets && b->cap_rows >= n_rows && b->cap_nnz >= nnz) return SDRB_OK;
+    free_batch_storage(b);
+    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
+    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_ids), nnz * sizeof(int32_t)));
+    if (nnz && unit) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_data), nnz * sizeof(float)));
+    b->cap_rows = n_rows;
+    b->cap_nnz = nnz;
+    return SDRB_OK;
 }
 
 // Device-side validation of a CSR pack that is already in HBM (one thread per row).
@@ -61,13 +84,16 @@ struct PackStats {
     uint32_t bad_offsets;   // 1 + first row whose offsets are not monotone / exceed nnz
     uint32_t bad_order;     // 1 + a row that is not strictly ascending
     uint32_t bad_payload;   // 1 + an element whose UnitData payload is outside [0,1]
+    uint32_t nnz;           // row_offsets[n_rows]
 };
 
 __global__ __launch_bounds__(256) void k_validate_pack(const uint32_t* __restrict__ off,
                                                        const int32_t* __restrict__ ids,
                                                        const float* __restrict__ data, uint64_t n_rows,
-                                                       uint32_t nnz, PackStats* __restrict__ st) {
+                                                       PackStats* __restrict__ st) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t nnz = off[n_rows];
+    if (r == 0) st->nnz = nnz;
     if (r >= n_rows) return;
     const uint32_t lo = off[r], hi = off[r + 1];
     if (hi < lo || hi > nnz || (r == 0 && lo != 0)) {
@@ -266,10 +292,10 @@ int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* ro
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    free_batch_storage(batch);
-    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
-    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_ids), nnz * sizeof(int32_t)));
-    if (nnz && unit) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_data), nnz * sizeof(float)));
+    {
+        const int rc = reserve_batch_storage(batch, n_rows, nnz);
+        if (rc != SDRB_OK) return rc;
+    }
     SDRB_HIP(hipMemcpyAsync(batch->d_offsets, off32.data(), (n_rows + 1) * sizeof(uint32_t),
                             hipMemcpyHostToDevice, s));
     if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -301,25 +327,27 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    uint32_t nnz = 0;
-    SDRB_HIP(hipMemcpyAsync(&nnz, row_offsets + n_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    SDRB_HIP(hipStreamSynchronize(s));
-    if (nnz > 0 && (!ids || (unit && !data))) {
-        set_error("ids (and payloads of a UnitData batch) must not be null");
-        return SDRB_ERR_INVALID_ARG;
+    if (!ids || (unit && !data)) {  // only an element-free batch may come without arrays
+        uint32_t total = 0;
+        SDRB_HIP(hipMemcpyAsync(&total, row_offsets + n_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        SDRB_HIP(hipStreamSynchronize(s));
+        if (total > 0) {
+            set_error("ids (and payloads of a UnitData batch) must not be null");
+            return SDRB_ERR_INVALID_ARG;
+        }
     }
-    PackStats init{0u, INT32_MAX, INT32_MIN, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    PackStats init{0u, INT32_MAX, INT32_MIN, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
     PackStats* d_st = static_cast<PackStats*>(workspace(batch->device, 2, sizeof(PackStats)));
     if (!d_st) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemcpyAsync(d_st, &init, sizeof init, hipMemcpyHostToDevice, s));
-    if (n_rows) {
-        hipLaunchKernelGGL(k_validate_pack, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, s,
-                           row_offsets, ids, unit ? data : nullptr, n_rows, nnz, d_st);
-        SDRB_HIP(hipGetLastError());
-    }
+    // one pass over the rows: total element count, row checks, id span (grid covers >= 1 thread)
+    hipLaunchKernelGGL(k_validate_pack, dim3((uint32_t)((n_rows + 256) / 256)), dim3(256), 0, s, row_offsets,
+                       ids, unit ? data : nullptr, n_rows, d_st);
+    SDRB_HIP(hipGetLastError());
     PackStats st;
     SDRB_HIP(hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, s));
     SDRB_HIP(hipStreamSynchronize(s));
+    const uint32_t nnz = st.nnz;
     if (st.bad_offsets != 0xFFFFFFFFu) {
         set_error("row_offsets not monotone (or row_offsets[0] != 0) at row %u", st.bad_offsets - 1);
         return SDRB_ERR_INVALID_ARG;
@@ -338,21 +366,50 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
                   batch->width);
         return SDRB_ERR_ID_RANGE;
     }
-    free_batch_storage(batch);
-    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
-    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_ids), (size_t)nnz * sizeof(int32_t)));
-    if (nnz && unit) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_data), (size_t)nnz * sizeof(float)));
+    {
+        const int rc = reserve_batch_storage(batch, n_rows, nnz);
+        if (rc != SDRB_OK) return rc;
+    }
     SDRB_HIP(hipMemcpyAsync(batch->d_offsets, row_offsets, (n_rows + 1) * sizeof(uint32_t),
                             hipMemcpyDeviceToDevice, s));
     if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     if (nnz && unit)
         SDRB_HIP(hipMemcpyAsync(batch->d_data, data, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
-    SDRB_HIP(hipStreamSynchronize(s));
     batch->n_rows = n_rows;
     batch->nnz = nnz;
     batch->max_row_len = st.max_len;
     batch->min_id = any ? st.min_id : 0;
     batch->max_id = any ? st.max_id : -1;
+    return SDRB_OK;
+}
+
+int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz, const uint32_t* row_offsets,
+                                const int32_t* ids, const float* data, uint32_t max_row_len,
+                                int32_t min_id, int32_t max_id) {
+    if (!batch || !row_offsets || (nnz && !ids) ||
+        (nnz && batch->data_kind == SDRB_DATA_UNIT && !data)) {
+        set_error("sdrb_batch_adopt_device_csr: null argument");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (nnz > 0xFFFFFFFFull || n_rows > 0xFFFFFFFEull) {
+        set_error("batch too large for 32-bit offsets");
+        return SDRB_ERR_OVERFLOW;
+    }
+    if (batch->width > 0 && nnz && (min_id < 0 || max_id >= batch->width)) {
+        set_error("id outside the declared width: ids span [%d, %d], width %d", min_id, max_id, batch->width);
+        return SDRB_ERR_ID_RANGE;
+    }
+    DeviceGuard guard(batch->device);
+    free_batch_storage(batch);
+    batch->owns_storage = false;
+    batch->d_offsets = const_cast<uint32_t*>(row_offsets);
+    batch->d_ids = const_cast<int32_t*>(ids);
+    batch->d_data = batch->data_kind == SDRB_DATA_UNIT ? const_cast<float*>(data) : nullptr;
+    batch->n_rows = n_rows;
+    batch->nnz = nnz;
+    batch->max_row_len = max_row_len;
+    batch->min_id = nnz ? min_id : 0;
+    batch->max_id = nnz ? max_id : -1;
     return SDRB_OK;
 }
 
@@ -368,6 +425,16 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
     if (width) *width = batch->width;
     if (data_kind) *data_kind = batch->data_kind;
     if (max_row_len) *max_row_len = batch->max_row_len;
+    return SDRB_OK;
+}
+
+int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id) {
+    if (!batch) {
+        set_error("null batch handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (min_id) *min_id = batch->min_id;
+    if (max_id) *max_id = batch->max_id;
     return SDRB_OK;
 }
 

@@ -20,6 +20,8 @@ struct sdrb_batch {
     uint32_t* d_offsets = nullptr;    // [n_rows + 1]
     int32_t* d_ids = nullptr;         // [nnz]
     float* d_data = nullptr;          // [nnz] or null
+    bool owns_storage = true;            // false: d_offsets/d_ids/d_data are views into caller memory
+    uint64_t cap_rows = 0, cap_nnz = 0;  // allocated capacity (rows, elements); storage is reused across uploads
     uint32_t* d_bitplanes = nullptr;  // derived, built on demand: word w of row j at [w*n_rows + j]
 };
 

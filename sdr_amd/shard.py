@@ -15,9 +15,58 @@ collectives without a GPU.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import numpy as np
+
+
+@dataclass(frozen=True)
+class QueryPlan:
+    """Everything a receiving rank needs to size, receive and adopt a packed query batch without
+    talking to the host of the sender: shape, payload kind and the validated batch's id statistics.
+    A front end distributes it out of band (it is six integers); the bench derives it on every
+    rank from the same synthetic generator."""
+    n_rows: int
+    nnz: int
+    has_data: bool
+    max_row_len: int
+    min_id: int
+    max_id: int
+
+    @property
+    def words(self) -> int:
+        return (self.n_rows + 1) + self.nnz * (2 if self.has_data else 1)
+
+
+@dataclass
+class PackedQueries:
+    """A validated query batch in its wire form: one int32 device tensor
+    ``[offsets (n_rows+1) | ids (nnz) | payload bits (nnz, UnitData only)]`` plus its plan."""
+    plan: QueryPlan
+    tensor: "object"
+
+    @classmethod
+    def from_host_csr(cls, off, ids, data, *, width: int, engine):
+        """Validates the batch by packing it once on this rank's device, then lays it out for
+        the wire."""
+        import torch
+        probe = engine.pack_host(off, ids, data, width)
+        st = probe.stats() if hasattr(probe, "stats") else _host_stats(off, ids, data)
+        plan = QueryPlan(st["n_rows"], st["nnz"], bool(st["has_data"]), st["max_row_len"], st["min_id"], st["max_id"])
+        parts = [np.asarray(off, dtype=np.uint64).astype(np.uint32).view(np.int32), np.asarray(ids, dtype=np.int32)]
+        if data is not None:
+            parts.append(np.asarray(data, dtype=np.float32).view(np.int32))
+        tensor = torch.from_numpy(np.concatenate(parts)).to(engine.torch_device())
+        return cls(plan, tensor)
+
+
+def _host_stats(off, ids, data):
+    off = np.asarray(off, dtype=np.uint64)
+    lens = np.diff(off)
+    return dict(n_rows=len(off) - 1, nnz=int(off[-1]), max_row_len=int(lens.max()) if len(lens) else 0,
+                min_id=int(ids.min()) if len(ids) else 0, max_id=int(ids.max()) if len(ids) else -1,
+                has_data=data is not None)
 
 
 def shard_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
@@ -45,10 +94,29 @@ class HipEngine:
         from .batch import SDRBatch
         return SDRBatch.from_csr(off, ids, data, width=width, device=self.device)
 
-    def pack_device(self, off_t, ids_t, data_t, width):
+    def pack_device(self, off_t, ids_t, data_t, width, into=None):
         from .batch import SDRBatch
-        b = SDRBatch(self.device, width, "unit" if data_t is not None else "empty")
-        b.upload_device(off_t, ids_t, data_t)
+        from ._lib import DATA_EMPTY, DATA_UNIT
+        kind = DATA_UNIT if data_t is not None else DATA_EMPTY
+        b = into if into is not None and into.data_kind == kind and into.width == width else None
+        if b is None:
+            b = SDRBatch(self.device, width, kind)
+        b.upload_device(off_t, ids_t, data_t)   # reuses the batch's device storage when it fits
+        return b
+
+    def adopt(self, tensor, plan: "QueryPlan", width, into=None):
+        """Zero-copy view of a received wire tensor as a query batch."""
+        import torch
+        from ._lib import DATA_EMPTY, DATA_UNIT
+        from .batch import SDRBatch
+        kind = DATA_UNIT if plan.has_data else DATA_EMPTY
+        b = into if into is not None and into.data_kind == kind and into.width == width else None
+        if b is None:
+            b = SDRBatch(self.device, width, kind)
+        nq, nnz = plan.n_rows, plan.nnz
+        data_t = tensor[nq + 1 + nnz:].view(torch.float32) if plan.has_data else None
+        b.adopt_device(tensor[: nq + 1], tensor[nq + 1: nq + 1 + nnz], data_t,
+                       max_row_len=plan.max_row_len, min_id=plan.min_id, max_id=plan.max_id)
         return b
 
     def size_op(self, name: str, queries, shard, out=None):
@@ -76,11 +144,14 @@ class ShardedDatabase:
         return cls(engine.pack_host(s_off, s_ids, s_data, width), lo, hi, n, width, engine, group)
 
     # -- the exchange step ------------------------------------------------------------
-    def broadcast_queries(self, packed=None, src: int = 0):
+    def broadcast_queries(self, packed=None, src: int = 0, force_collective: bool = False, into=None):
         """Broadcasts a packed query batch from ``src`` and packs it on every rank.
 
         ``packed`` (needed on ``src`` only) is ``(offsets, ids, data_or_None)`` as torch tensors
         on the engine's device: int32 offsets [nq+1], int32 ids, float32 payloads.
+        ``force_collective`` runs the collectives even in a one-rank group (used to rehearse the
+        RCCL path on a single GPU).  ``into`` recycles an earlier query batch of the same payload
+        kind (its device storage is reused when large enough).
         """
         import torch
         import torch.distributed as dist
@@ -88,9 +159,9 @@ class ShardedDatabase:
         dev = self.engine.torch_device()
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
-        if world == 1:
+        if world == 1 and not (force_collective and dist.is_initialized()):
             off_t, ids_t, data_t = packed
-            return self.engine.pack_device(off_t, ids_t, data_t, self.width)
+            return self._pack(off_t, ids_t, data_t, into)
         header = torch.zeros(3, dtype=torch.int64, device=dev)
         if rank == src:
             off_t, ids_t, data_t = packed
@@ -107,8 +178,39 @@ class ShardedDatabase:
         off_t = buf[: nq + 1]
         ids_t = buf[nq + 1: nq + 1 + nnz]
         data_t = buf[nq + 1 + nnz:].view(torch.float32) if has_data else None
-        return self.engine.pack_device(off_t.contiguous(), ids_t.contiguous(),
-                                       None if data_t is None else data_t.contiguous(), self.width)
+        return self._pack(off_t.contiguous(), ids_t.contiguous(),
+                          None if data_t is None else data_t.contiguous(), into)
+
+    def broadcast_packed(self, packed: Optional[PackedQueries], plan: QueryPlan, src: int = 0,
+                         force_collective: bool = False, recv=None, into=None):
+        """Fast path of the exchange step when every rank knows the plan of the batch: ONE
+        collective (the wire tensor), no host round trip, and the received tensor is adopted as
+        the query batch without copying or re-validating it (the sender validated it).
+        ``recv`` is an optional preallocated int32 tensor of ``plan.words`` elements."""
+        import torch
+        import torch.distributed as dist
+
+        on = dist.is_initialized()
+        world = dist.get_world_size(self.group) if on else 1
+        rank = dist.get_rank(self.group) if on else 0
+        if rank == src:
+            tensor = packed.tensor
+            if tensor.numel() != plan.words:
+                raise ValueError("packed tensor does not match the plan")
+        else:
+            tensor = recv if recv is not None else torch.empty(plan.words, dtype=torch.int32,
+                                                               device=self.engine.torch_device())
+        if world > 1 or (force_collective and on):
+            dist.broadcast(tensor, src=src, group=self.group)
+        return self.engine.adopt(tensor, plan, self.width, into=into)
+
+    def _pack(self, off_t, ids_t, data_t, into):
+        if into is not None:
+            try:
+                return self.engine.pack_device(off_t, ids_t, data_t, self.width, into=into)
+            except TypeError:   # engines without storage reuse
+                pass
+        return self.engine.pack_device(off_t, ids_t, data_t, self.width)
 
     # -- per-shard evaluation ----------------------------------------------------------
     def size_op(self, name: str, queries, out=None):

@@ -286,3 +286,30 @@ def test_popcount_kernel_vs_oracle(width, max_len, nq, nd, au):
     else:   # `this` would be UnitData: payload-dependent, popcount must refuse
         with pytest.raises(sdr_amd.SdrbError):
             gpu_sizes(RM, dt, da, swap=True, algo="popcount")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_data", [False, True])
+def test_adopted_view_equals_uploaded_batch(with_data):
+    """A zero-copy view of caller tensors (wire form of the query exchange) must behave exactly
+    like a validated upload of the same rows, for size ops and element ops, and re-adopting a
+    smaller batch into the same handle must not leave stale state behind."""
+    import torch
+    from sdr_amd.shard import HipEngine, PackedQueries
+    rng = np.random.default_rng(77)
+    eng = HipEngine(0)
+    d_off, d_ids, d_data = util.ragged_rows(rng, 500, 2048, 40, with_data)
+    db = SDRBatch.from_csr(d_off, d_ids, d_data, width=2048)
+    view = None
+    for nq in (70, 9):
+        q_off, q_ids, q_data = util.ragged_rows(rng, nq, 2048, 40, with_data)
+        up = SDRBatch.from_csr(q_off, q_ids, q_data, width=2048)
+        wire = PackedQueries.from_host_csr(q_off, q_ids, q_data, width=2048, engine=eng)
+        assert wire.plan.words == wire.tensor.numel()
+        view = eng.adopt(wire.tensor, wire.plan, 2048, into=view)
+        assert view.stats() == up.stats()
+        for name in ("ands", "ors", "xors", "rms"):
+            assert torch.equal(getattr(view, name)(db), getattr(up, name)(db)), name
+        a, b = view.xore(db).to_host(), up.xore(db).to_host()
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or np.array_equal(x, y)

@@ -18,7 +18,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 import util  # noqa: E402
-from sdr_amd.shard import ShardedDatabase, shard_range, slice_csr  # noqa: E402
+from sdr_amd.shard import PackedQueries, ShardedDatabase, shard_range, slice_csr  # noqa: E402
 
 OPS = {"ands": 0, "ors": 1, "xors": 2, "rms": 3}
 
@@ -37,6 +37,11 @@ class OracleEngine:
         import oracle
         return oracle.Batch(off_t.numpy().astype(np.uint64), ids_t.numpy(),
                             None if data_t is None else data_t.numpy())
+
+    def adopt(self, tensor, plan, width, into=None):
+        nq, nnz = plan.n_rows, plan.nnz
+        data_t = tensor[nq + 1 + nnz:].view(torch.float32) if plan.has_data else None
+        return self.pack_device(tensor[: nq + 1], tensor[nq + 1: nq + 1 + nnz], data_t, width)
 
     def size_op(self, name, queries, shard, out=None):
         import oracle
@@ -71,6 +76,11 @@ def _worker(rank, world, port, with_data, n_rows, results):
             local = db.size_op(name, queries)
             assert local.shape == (9, db.row_hi - db.row_lo)
             out[name] = db.gather_counts(local).numpy()
+        # the one-collective path: every rank knows the plan, only the wire tensor travels
+        wire = PackedQueries.from_host_csr(q_off, q_ids, q_data, width=300, engine=OracleEngine())
+        assert wire.plan.words == wire.tensor.numel()
+        again = db.broadcast_packed(wire if rank == 0 else None, wire.plan, src=0)
+        assert np.array_equal(db.gather_counts(db.size_op("xors", again)).numpy(), out["xors"])
         counts, rows = db.topk(db.size_op("ands", queries), 5)
         out["topk_counts"], out["topk_rows"] = counts.numpy(), rows.numpy()
         if rank == 0:
