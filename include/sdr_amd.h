@@ -138,6 +138,21 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
                  uint32_t* out, uint64_t ld_out, void* stream);
 
 /*
+ * All-pairs overlap with a fused per-row top-k.  For every row i of `a`, the k rows j of `b`
+ * with the largest id overlap |a_i and b_j| -- the value `ands` returns for EmptyData elements
+ * (SDR.hpp:1083-1095; payloads of UnitData batches are ignored here) -- ordered by overlap
+ * descending, then j ascending.  The reference has no top-k: each count is pinned by `ands`,
+ * the selection and its tie rule are this engine's own.  The na x nb count matrix is never
+ * materialised.  When exclude_offset >= 0 the pair (i, j = i + exclude_offset) is skipped (the
+ * self match when `a` is rows [exclude_offset, exclude_offset + na) of `b`).
+ * out_counts / out_rows: device memory, [a rows][k]; unused slots hold count 0, row -1.
+ * Kernel: dense int8 0/1 product on the matrix cores (v_mfma_i32_32x32x32_i8).  Needs declared
+ * widths <= 16384, k <= 16 and rows shorter than 4096 ids on at least one side.
+ */
+int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
+                       unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream);
+
+/*
  * Element operations for every pair, as a two-call CSR protocol:
  *   SDRB_OP_AND -> ande (SDR.hpp:999-1025)       SDRB_OP_OR -> ore  (SDR.hpp:1183-1222)
  *   SDRB_OP_XOR -> xore (SDR.hpp:1307-1349)      SDRB_OP_RM -> rme  (SDR.hpp:1515-1566)

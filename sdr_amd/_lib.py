@@ -51,6 +51,7 @@ PROTOTYPES = {
     "sdrb_batch_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sdrb_batch_destroy": (C.c_int, [_vp]),
     "sdrb_size_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
+    "sdrb_allpairs_topk": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int64, C.c_uint, _vp, _vp, _vp]),
     "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
     "sdrb_elem_op_fill": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),
     "sdrb_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),

@@ -215,6 +215,20 @@ class SDRBatch:
                                      _stream_handle(other.device, stream)))
         return out
 
+    def allpairs_topk(self, other: "SDRBatch", k: int, *, exclude_offset: int = -1, stream=None):
+        """For every row i of ``self``: the ``k`` rows j of ``other`` with the largest id overlap
+        (``self[i].ands(other[j])`` on EmptyData views), overlap descending then j ascending.
+        ``exclude_offset >= 0`` skips the pair (i, i + exclude_offset).  Returns
+        ``(counts, rows)``: int32 ``[len(self), k]`` tensors on the device; unused slots are
+        (0, -1).  The full count matrix is never materialised."""
+        torch = _torch()
+        dev = f"cuda:{other.device}"
+        counts = torch.empty((max(self.n_rows, 1), k), dtype=torch.int32, device=dev)[: self.n_rows]
+        rows = torch.empty((max(self.n_rows, 1), k), dtype=torch.int32, device=dev)[: self.n_rows]
+        check(self._lib.sdrb_allpairs_topk(self._h, other._h, k, exclude_offset, 0, counts.data_ptr(),
+                                           rows.data_ptr(), _stream_handle(other.device, stream)))
+        return counts, rows
+
     def ands(self, other, *, swap=False, out=None, stream=None, algo=None):
         """``out[i, j] = self[i].ands(other[j])`` (uint32 counts in an int32 tensor)."""
         return self._size_op(OP_AND, other, swap, out, stream, algo)

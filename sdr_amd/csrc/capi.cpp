@@ -37,6 +37,14 @@ struct Scratch {
 std::mutex g_ws_mutex;
 std::map<std::pair<int, int>, Scratch> g_ws;
 
+// Data derived from the rows (bit planes, dense byte matrix) dies with the content it was built from.
+void drop_derived(sdrb_batch* b) {
+    if (b->d_bitplanes) (void)hipFree(b->d_bitplanes);
+    if (b->d_dense8) (void)hipFree(b->d_dense8);
+    b->d_bitplanes = nullptr;
+    b->d_dense8 = nullptr;
+}
+
 void free_batch_storage(sdrb_batch* b) {
     if (b->owns_storage) {
         if (b->d_offsets) (void)hipFree(b->d_offsets);
@@ -44,8 +52,7 @@ void free_batch_storage(sdrb_batch* b) {
         if (b->d_data) (void)hipFree(b->d_data);
     }
     b->owns_storage = true;
-    if (b->d_bitplanes) (void)hipFree(b->d_bitplanes);
-    b->d_bitplanes = nullptr;
+    drop_derived(b);
     b->d_offsets = nullptr;
     b->d_ids = nullptr;
     b->d_data = nullptr;
@@ -62,10 +69,7 @@ void free_batch_storage(sdrb_batch* b) {
 // hipMalloc/hipFree).  Derived data of the previous content is dropped.
 int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
     const bool unit = b->data_kind == SDRB_DATA_UNIT;
-    if (b->d_bitplanes) {
-        (void)hipFree(b->d_bitplanes);
-        b->d_bitplanes = nullptr;
-    }
+    drop_derived(b);
     if (b->owns_storage && b->d_offsets && b->cap_rows >= n_rows && b->cap_nnz >= nnz) return SDRB_OK;
     free_batch_storage(b);
     SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
@@ -497,6 +501,28 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
     }
     return launch_size_merge(a, b, op, swap, out, ld_out, s);
+}
+
+int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
+                       unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
+    (void)flags;
+    int rc = check_pair(a, b, SDRB_OP_AND);
+    if (rc != SDRB_OK) return rc;
+    if (k == 0 || !out_counts || !out_rows) {
+        set_error("sdrb_allpairs_topk: k is 0 or an output is null");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (a->n_rows == 0) return SDRB_OK;
+    if (!allpairs_mfma_applicable(a, b, k)) {
+        set_error("sdrb_allpairs_topk needs declared widths <= 16384, k <= 16 and rows shorter than 4096 ids");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_allpairs_mfma(a, b, k, exclude_offset, out_counts, out_rows, static_cast<hipStream_t>(stream));
 }
 
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,

@@ -23,6 +23,8 @@ struct sdrb_batch {
     bool owns_storage = true;            // false: d_offsets/d_ids/d_data are views into caller memory
     uint64_t cap_rows = 0, cap_nnz = 0;  // allocated capacity (rows, elements); storage is reused across uploads
     uint32_t* d_bitplanes = nullptr;  // derived, built on demand: word w of row j at [w*n_rows + j]
+    uint8_t* d_dense8 = nullptr;      // derived, built on demand: 0/1 bytes in MFMA fragment order (allpairs_mfma.hip)
+    uint32_t dense_chunks = 0;        // width of d_dense8 in 64-id chunks
 };
 
 namespace sdrb {
@@ -30,7 +32,8 @@ namespace sdrb {
 void set_error(const char* fmt, ...);
 
 // Per-device scratch that grows on demand and lives until process exit.
-// slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A.
+// slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
+// slot 4: partial top-k lists.
 void* workspace(int device, int slot, size_t bytes);
 
 #define SDRB_HIP(call)                                                                   \
@@ -77,6 +80,12 @@ int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool sw
 bool popcount_applicable(const sdrb_batch* a, const sdrb_batch* b);
 int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                          uint32_t* out, uint64_t ld_out, hipStream_t stream);
+
+// allpairs_mfma.hip / allpairs_topk ----------------------------------------------------
+// For every row i of a: the k rows j of b with the largest id overlap (count desc, row asc).
+bool allpairs_mfma_applicable(const sdrb_batch* a, const sdrb_batch* b, uint32_t k);
+int launch_allpairs_mfma(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
+                         uint32_t* out_counts, int32_t* out_rows, hipStream_t stream);
 
 // unit_table.hip --------------------------------------------------------------------
 // Wave-per-row kernels with an LDS position table of one row of A (declared width <= 32768).
