@@ -29,10 +29,12 @@ namespace {
 
 using i32x4 = int __attribute__((ext_vector_type(4)));
 using i32x16 = int __attribute__((ext_vector_type(16)));
+// native vectors (not the HIP uint4 struct) so staging arrays stay in registers
 
 constexpr int kPanel = 256;          // rows per panel
 constexpr int kChunk = 64;           // ids per chunk
 constexpr int kPieceVec = 1024;      // 16-byte vectors per (panel, chunk) piece
+constexpr int kStageVec = 2048;      // vectors per operand per pipeline stage: two chunks of one panel
 constexpr int kKeyShift = 19;        // key = count << 19 | (2^19 - 1 - local j)
 constexpr int kLowMask = (1 << kKeyShift) - 1;
 constexpr uint32_t kMaxSplitRows = (uint32_t)kLowMask - 1;   // local j < 2^19 - 1 keeps keys > 0
@@ -54,37 +56,57 @@ __global__ __launch_bounds__(256) void k_densify(const uint32_t* __restrict__ of
     for (uint32_t k = lane; k < len; k += 64) dense[dense_offset(row, (uint32_t)ids[beg + k], n_chunks)] = 1;
 }
 
-// Sorted (descending) insertion into one lane's list, kept in LDS as list[slot * 256]: a lane
-// touches only its own column, so no synchronisation is involved.  Returns the new last entry.
+// Sorted (descending) insertion into one lane's register-resident list.  A key that does not beat
+// the last entry falls through unchanged, so the call is harmless for lanes without a candidate.
 template <int LIST>
-__device__ __forceinline__ int list_insert(int* list, int key) {
-    int cur[LIST];
-#pragma unroll
-    for (int s = 0; s < LIST; ++s) cur[s] = list[s * 256];
+__device__ __forceinline__ void list_insert(int (&list)[LIST], int key) {
 #pragma unroll
     for (int s = 0; s < LIST; ++s) {
-        const int hi = cur[s] > key ? cur[s] : key;
-        key = cur[s] > key ? key : cur[s];
-        cur[s] = hi;
+        const int hi = list[s] > key ? list[s] : key;
+        key = list[s] > key ? key : list[s];
+        list[s] = hi;
     }
-#pragma unroll
-    for (int s = 0; s < LIST; ++s) list[s * 256] = cur[s];
-    return cur[LIST - 1];
 }
 
 // Accumulator register `reg` of lane half h holds row (reg & 3) + 8 * (reg >> 2) + 4 * h of the 32 x 32 tile.
 
+// LDS-DMA of one stage (two consecutive 16 KiB pieces of a panel, 2048 vectors) for both operands:
+// lane l of wave w moves vector 64 w + 256 m + l, the LDS side being wave-uniform base + 16 l.
+__device__ __forceinline__ void stage_dma(const i32x4* __restrict__ src_j, const i32x4* __restrict__ src_i,
+                                          i32x4* dst_j, i32x4* dst_i, uint32_t tid, uint32_t wave) {
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_global_load_lds((gptr)(src_j + tid + 256 * m), (lptr)(dst_j + wave * 64 + 256 * m), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(src_i + tid + 256 * m), (lptr)(dst_i + wave * 64 + 256 * m), 16, 0, 0);
+    }
+}
+
+#ifdef SDRB_AP_EXP_STAMPS   // diagnostic build only: cycles of block 0 / wave 0 spent in each phase
+}  // (leave the unnamed namespace so the symbol is sdrb::g_ap_stamps)
+__device__ unsigned long long g_ap_stamps[8];
+namespace {
+#define AP_STAMP(slot, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ap_stamps[slot] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define AP_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define AP_STAMP(slot, t0) do { (void)(t0); } while (0)
+#define AP_NOW() 0ull
+#endif
+
 template <int LIST>
 __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
-    const uint4* __restrict__ dense_i, const uint4* __restrict__ dense_j, uint32_t n_ipanels, uint32_t n_jpanels,
+    const i32x4* __restrict__ dense_i, const i32x4* __restrict__ dense_j, uint32_t n_ipanels, uint32_t n_jpanels,
     uint32_t n_chunks, uint32_t splits, uint32_t panels_per_split, uint32_t nb, long long excl,
     int* __restrict__ partial) {
-    __shared__ uint4 lds[2][2][kPieceVec];   // [buffer][0 = j operand, 1 = i operand]
-    __shared__ int lists[4][LIST][256];      // [i tile of the wave][slot][thread]: sorted keys, 0 = empty
+    __shared__ i32x4 lds[2][2][kStageVec];   // [buffer][0 = j operand, 1 = i operand], one stage = 128 ids deep
+    // per row i of the panel: a count that 16 candidates of ONE of its lists already reach, so a
+    // candidate with a smaller count cannot be among the block's best 16 (equal counts still can)
+    __shared__ int shared_level[kPanel];
 
-    // block -> (i panel, j split): the 8 XCDs take blocks round-robin, so consecutive slots of one
-    // XCD get the 8 splits of one i panel (they share that panel's chunks in the XCD's L2) and
-    // different XCDs get different i panels.
+    // block -> (i panel, j split): the 8 XCDs take blocks round-robin; one XCD works on panels
+    // ip = xcd, xcd + 8, ... and all their splits, so the blocks of an XCD stream the same j panels
+    // through its L2 at about the same time.
     const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const uint32_t split = slot % splits;
     const uint32_t ip = (slot / splits) * 8 + xcd;
@@ -96,19 +118,26 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
     const uint32_t wm = wave >> 1, wn = wave & 1;     // wave tile: j rows [128 wm, +128), i rows [128 wn, +128)
     const uint32_t half = lane >> 5, col = lane & 31;
 
-    int thr[4];   // last (smallest) entry of each list
+    int list[4][LIST];   // per i tile of the wave: this lane's sorted keys, 0 = empty
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        thr[nt] = 0;
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int s = 0; s < LIST; ++s) lists[nt][s][tid] = 0;
-    }
+        for (int s = 0; s < LIST; ++s) list[nt][s] = 0;
+    shared_level[tid] = 0;
 
-    const uint4* gi = dense_i + (uint64_t)ip * n_chunks * kPieceVec;
+    const i32x4* gi = dense_i + (uint64_t)ip * n_chunks * kPieceVec;
     const long long i_lo = (long long)ip * kPanel + wn * 128;   // first row i of this wave
+    const uint32_t n_stages = n_chunks / 2;                     // the host pads the matrices to an even chunk count
+
+    // One stream of (panel, stage) pieces: while a stage is multiplied out of one LDS buffer the next
+    // one -- at the end of a panel, the first stage of the next j panel -- is copied HBM -> LDS by
+    // the DMA path (no staging registers, no ds_write); __syncthreads() also waits for the copy.
+    if (jp_begin < jp_end)
+        stage_dma(dense_j + (uint64_t)jp_begin * n_chunks * kPieceVec, gi, &lds[0][0][0], &lds[0][1][0], tid, wave);
+    __syncthreads();
+    uint32_t buf = 0;
 
     for (uint32_t jp = jp_begin; jp < jp_end; ++jp) {
-        const uint4* gj = dense_j + (uint64_t)jp * n_chunks * kPieceVec;
         i32x16 acc[4][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -116,123 +145,169 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0;
-
-        uint4 stage[8];
+        const bool last_panel = jp + 1 == jp_end;
+        const unsigned long long t_loop = AP_NOW();
+        for (uint32_t st = 0; st < n_stages; ++st) {
+            const bool last_stage = st + 1 == n_stages;
+#ifdef SDRB_AP_EXP_NO_DMA   // timing experiment: multiply whatever the buffers hold
+            if (false) {
+#else
+            if (!(last_stage && last_panel)) {
+#endif
+                // the other buffer was last read (or used as parking space) before the previous barrier
+                const uint32_t st_next = last_stage ? 0 : st + 1;
+                stage_dma(dense_j + ((uint64_t)(last_stage ? jp + 1 : jp) * n_chunks + 2 * st_next) * kPieceVec,
+                          gi + (uint64_t)(2 * st_next) * kPieceVec, &lds[buf ^ 1][0][0], &lds[buf ^ 1][1][0], tid, wave);
+            }
+#ifdef SDRB_AP_EXP_NO_MFMA   // timing experiment: operand delivery only
+            __syncthreads();
+            buf ^= 1;
+            continue;
+#endif
+            i32x4 fa[2][4], fb[2][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            stage[m] = gj[tid + 256 * m];
-            stage[4 + m] = gi[tid + 256 * m];
-        }
-        __syncthreads();   // every wave is done reading both buffers of the previous panel
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            lds[0][0][tid + 256 * m] = stage[m];
-            lds[0][1][tid + 256 * m] = stage[4 + m];
-        }
-        __syncthreads();
-
-        for (uint32_t c = 0; c < n_chunks; ++c) {
-            const uint32_t buf = c & 1;
-            const bool more = c + 1 < n_chunks;
-            if (more) {
-                const uint4* nj = gj + (uint64_t)(c + 1) * kPieceVec;
-                const uint4* ni = gi + (uint64_t)(c + 1) * kPieceVec;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    stage[m] = nj[tid + 256 * m];
-                    stage[4 + m] = ni[tid + 256 * m];
-                }
+            for (int t = 0; t < 4; ++t) {
+                fa[0][t] = lds[buf][0][((wm * 4 + t) * 2) * 64 + lane];
+                fb[0][t] = lds[buf][1][((wn * 4 + t) * 2) * 64 + lane];
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                i32x4 fa[4], fb[4];
+            for (int s = 0; s < 4; ++s) {   // four 32-deep steps per stage; fragments of step s+1 load during step s
+                if (s < 3) {
+                    const int sn = s + 1;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint4 va = lds[buf][0][((wm * 4 + t) * 2 + s) * 64 + lane];
-                    const uint4 vb = lds[buf][1][((wn * 4 + t) * 2 + s) * 64 + lane];
-                    fa[t] = i32x4{(int)va.x, (int)va.y, (int)va.z, (int)va.w};
-                    fb[t] = i32x4{(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
+                    for (int t = 0; t < 4; ++t) {
+                        fa[sn & 1][t] = lds[buf][0][(sn >> 1) * kPieceVec + ((wm * 4 + t) * 2 + (sn & 1)) * 64 + lane];
+                        fb[sn & 1][t] = lds[buf][1][(sn >> 1) * kPieceVec + ((wn * 4 + t) * 2 + (sn & 1)) * 64 + lane];
+                    }
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-            }
-            if (more) {
-                // buffer buf^1 was last read in iteration c-1; every wave has passed the barrier since
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    lds[buf ^ 1][0][tid + 256 * m] = stage[m];
-                    lds[buf ^ 1][1][tid + 256 * m] = stage[4 + m];
-                }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt], 0, 0, 0);
             }
             __syncthreads();
+            buf ^= 1;
         }
 
-        // ---- epilogue: fold this 128 x 128 wave tile into the per-lane top-k lists
-        const uint32_t j_local0 = (jp - jp_begin) * kPanel + wm * 128 + 4 * half;   // local j of (mt 0, reg 0)
-        const long long j_lo = (long long)jp * kPanel + wm * 128;                    // first global j of the wave tile
-        const bool tail = j_lo + 127 >= (long long)nb;
-        const bool diag = excl >= 0 && j_lo <= i_lo + 127 + excl && i_lo + excl <= j_lo + 127;
-        // Padding rows of the last panel and the excluded pair are never candidates.  With r = row of
-        // the wave tile that lane half 0 holds in a slot, both tests are against lane constants.
-        const int pad_from = tail ? (int)((long long)nb - j_lo) - 4 * (int)half : (1 << 30);
-        const int skip_base = diag ? (int)(i_lo + excl - j_lo) + (int)col - 4 * (int)half : -(1 << 30);
-        const int low_base = kLowMask - (int)j_local0;
-        // The operand buffers are idle until the barrier at the top of the next panel: each wave
-        // parks one i tile's 64 counts per lane (4 j tiles x 16 registers) in its own quarter of them,
-        // straight from the accumulators, and walks them in a rolled loop.  The counts therefore
-        // never need VALU-visible registers while the matrix pipeline owns the register file.
-        i32x4* park = reinterpret_cast<i32x4*>(&lds[0][0][0]) + wave * 1024 + lane;   // [slot/4][lane]
+        AP_STAMP(0, t_loop);
+        const unsigned long long t_epi = AP_NOW();
+        // ---- epilogue (once per j panel): fold this 128 x 128 wave tile into the per-lane top-k lists
+#ifndef SDRB_AP_EXP_NO_EPILOGUE
+        {
+            const uint32_t j_local0 = (jp - jp_begin) * kPanel + wm * 128 + 4 * half;   // local j of (mt 0, reg 0)
+            const long long j_lo = (long long)jp * kPanel + wm * 128;                    // first global j of the wave tile
+            const bool tail = j_lo + 127 >= (long long)nb;
+            const bool diag = excl >= 0 && j_lo <= i_lo + 127 + excl && i_lo + excl <= j_lo + 127;
+            // Padding rows of the last panel and the excluded pair are never candidates.  With r = row of
+            // the wave tile that lane half 0 holds in a slot, both tests are against lane constants.
+            const int pad_from = tail ? (int)((long long)nb - j_lo) - 4 * (int)half : (1 << 30);
+            const int skip_base = diag ? (int)(i_lo + excl - j_lo) + (int)col - 4 * (int)half : -(1 << 30);
+            const int low_base = kLowMask - (int)j_local0;
+            // The buffer that was just multiplied is idle until the next barrier: each wave parks one i
+            // tile's 64 counts per lane (4 j tiles x 16 registers) in its own quarter of it, straight from
+            // the accumulators, and walks them in a rolled loop.  The counts therefore never need
+            // VALU-visible registers while the matrix pipeline owns the register file.
+            i32x4* park = &lds[buf ^ 1][0][0] + wave * 1024 + lane;   // [slot / 4][lane]
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            __builtin_amdgcn_sched_barrier(0);   // keep each i tile's accumulator reads next to their stores
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned long long t_park = AP_NOW();
+                __builtin_amdgcn_sched_barrier(0);   // keep these accumulator reads next to their stores
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    park[(mt * 4 + q) * 64] = i32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2],
-                                                    acc[mt][nt][4 * q + 3]};
-            __builtin_amdgcn_sched_barrier(0);
-            const int skip_at = skip_base + nt * 32;
-            int m = -1;
-            if (tail || diag) {
+                    for (int q = 0; q < 4; ++q) {
+                        const i32x16& t16 = acc[mt][nt];
+                        park[(mt * 4 + q) * 64] = i32x4{t16[4 * q], t16[4 * q + 1], t16[4 * q + 2], t16[4 * q + 3]};
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                AP_STAMP(3, t_park);
+                const unsigned long long t_pre = AP_NOW();
+#ifdef SDRB_AP_EXP_PARK_ONLY   // timing experiment: stop after parking
+                if (park[0][0] == 0x7fffffff) list[nt][0] = 1;
+                continue;
+#endif
+                const int skip_at = skip_base + nt * 32;
+                int* level_slot = &shared_level[wn * 128 + nt * 32 + col];
+                const int level = __hip_atomic_load(level_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int m = -1;
+                if (tail || diag) {
 #pragma nounroll
-                for (int g = 0; g < 16; ++g) {   // slot group g: rows (g/4)*32 + 8*(g%4) + 0..3
-                    i32x4 v = park[g * 64];
-                    const int r0 = (g >> 2) * 32 + (g & 3) * 8;
+                    for (int g = 0; g < 16; ++g) {   // slot group g: rows (g/4)*32 + 8*(g%4) + 0..3
+                        i32x4 v = park[g * 64];
+                        const int r0 = (g >> 2) * 32 + (g & 3) * 8;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (r0 + x >= pad_from || r0 + x == skip_at) v[x] = -1;
-                    park[g * 64] = v;
+                        for (int x = 0; x < 4; ++x)
+                            if (r0 + x >= pad_from || r0 + x == skip_at) v[x] = -1;
+                        park[g * 64] = v;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) m = v[x] > m ? v[x] : m;
+                        for (int x = 0; x < 4; ++x) m = v[x] > m ? v[x] : m;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const i32x4 v = park[g * 64];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) m = v[x] > m ? v[x] : m;
+                    }
                 }
-            } else {
+                // Candidates reach a lane in ascending j, so on equal counts the earlier one stays: a new
+                // one must beat the count of the list's last entry, and reach the block's shared level.
+                const int last = list[nt][LIST - 1];
+                const int own = last == 0 ? 0 : (last >> kKeyShift) + 1;
+                const int need = own > level ? own : level;
+#ifdef SDRB_AP_EXP_PREFILTER_ONLY   // timing experiment: stop after the prefilter
+                if (m == 0x7fffffff) list[nt][0] = need;
+                continue;
+#endif
+                AP_STAMP(4, t_pre);
+                if (__builtin_amdgcn_ballot_w64(m >= need) == 0) continue;
+                const unsigned long long t_det = AP_NOW();
+                // per lane: which of its 64 parked slots qualify (slot order = ascending j) ...
+                uint32_t pass_lo = 0, pass_hi = 0;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const i32x4 v = park[g * 64];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) m = v[x] > m ? v[x] : m;
-                }
-            }
-            // candidates reach a lane in ascending j, so on equal counts the earlier one stays
-            const bool trigger = m >= 0 && (thr[nt] == 0 || m > (thr[nt] >> kKeyShift));
-            if (__builtin_amdgcn_ballot_w64(trigger) == 0) continue;
-#pragma nounroll
-            for (int g = 0; g < 16; ++g) {
-                const i32x4 v = park[g * 64];
-                const int low = low_base - ((g >> 2) * 32 + (g & 3) * 8);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int key = v[x] < 0 ? -1 : (v[x] << kKeyShift) + (low - x);
-                    if (__builtin_amdgcn_ballot_w64(key > thr[nt]) != 0) {
-                        if (key > thr[nt]) thr[nt] = list_insert<LIST>(&lists[nt][0][tid], key);
+                    for (int x = 0; x < 4; ++x) {
+                        const uint32_t bit = v[x] >= need ? (1u << ((g * 4 + x) & 31)) : 0u;
+                        if (g < 8) pass_lo |= bit;
+                        else pass_hi |= bit;
                     }
                 }
+                // ... then one insertion round per set bit of the busiest lane (usually one or two)
+                const int* park_dw = reinterpret_cast<const int*>(park);
+                while (__builtin_amdgcn_ballot_w64((pass_lo | pass_hi) != 0) != 0) {
+                    int key = -1;
+                    if ((pass_lo | pass_hi) != 0) {
+                        const int slot = pass_lo ? __builtin_ctz(pass_lo) : 32 + __builtin_ctz(pass_hi);
+                        if (pass_lo) pass_lo &= pass_lo - 1;
+                        else pass_hi &= pass_hi - 1;
+                        const int g = slot >> 2, x = slot & 3;
+                        const int count = park_dw[g * 256 + x];   // vector g of this lane, element x
+                        key = (count << kKeyShift) + (low_base - ((g >> 2) * 32 + (g & 3) * 8 + x));
+                    }
+                    list_insert<LIST>(list[nt], key);
+                }
+                AP_STAMP(5, t_det);
+                const int now = list[nt][LIST - 1];
+                if (now != last && (now >> kKeyShift) > level) atomicMax(level_slot, now >> kKeyShift);
             }
         }
+#else
+        {   // timing experiment only: keep every tile's product alive without the top-k work
+            int z = 0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) z += acc[mt][nt][0];
+            if (z == 0x7fffffff) list[0][0] = z;
+        }
+#endif
+        AP_STAMP(1, t_epi);
+        const unsigned long long t_bar = AP_NOW();
+        __syncthreads();   // nobody may refill the parking buffer while a wave still walks its counts
+        AP_STAMP(2, t_bar);
     }
 
     // partial lists: [row i][split][wm*2 + half][LIST]
@@ -241,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
         const uint64_t i = (uint64_t)ip * kPanel + wn * 128 + nt * 32 + col;
         int* dst = partial + ((i * splits + split) * kSubLists + (wm * 2 + half)) * LIST;
 #pragma unroll
-        for (int s = 0; s < LIST; ++s) dst[s] = lists[nt][s][tid];
+        for (int s = 0; s < LIST; ++s) dst[s] = list[nt][s];
     }
 }
 
@@ -308,16 +383,21 @@ int ensure_dense(const sdrb_batch* b, uint32_t n_chunks, hipStream_t stream) {
 template <int LIST>
 int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint32_t* out_counts,
         int32_t* out_rows, hipStream_t stream) {
-    const uint32_t n_chunks = chunks_of(a) > chunks_of(b) ? chunks_of(a) : chunks_of(b);
+    // common chunk count of both byte matrices, even (the kernel consumes two chunks per stage)
+    const uint32_t n_chunks = ((chunks_of(a) > chunks_of(b) ? chunks_of(a) : chunks_of(b)) + 1) / 2 * 2;
     int rc = ensure_dense(a, n_chunks, stream);
     if (rc != SDRB_OK) return rc;
     rc = ensure_dense(b, n_chunks, stream);
     if (rc != SDRB_OK) return rc;
     const uint32_t n_ipanels = (uint32_t)((a->n_rows + kPanel - 1) / kPanel);
     const uint32_t n_jpanels = (uint32_t)((b->n_rows + kPanel - 1) / kPanel);
-    // j-splits: enough blocks to fill 256 CUs, at most 8 (the L2 sharing pattern), each within the key range
+    // j-splits: as few as fill the 256 CUs (every split keeps its own candidate lists, whose warm-up
+    // is the expensive part of the epilogue), each within the key range
     uint32_t splits = 1;
-    while (splits < 8 && (uint64_t)n_ipanels * splits < 512 && splits * 2 <= n_jpanels) splits *= 2;
+    while (splits < 8 && (uint64_t)((n_ipanels + 7) / 8 * 8) * splits < 256 && splits * 2 <= n_jpanels) splits *= 2;
+#ifdef SDRB_AP_FORCE_SPLITS   // tuning experiments only
+    splits = SDRB_AP_FORCE_SPLITS;
+#endif
     uint32_t pps = (n_jpanels + splits - 1) / splits;
     while ((uint64_t)pps * kPanel > kMaxSplitRows) {
         splits *= 2;
@@ -328,7 +408,7 @@ int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint
     int* partial = static_cast<int*>(workspace(b->device, 4, pbytes));
     if (!partial) return SDRB_ERR_HIP;
     hipLaunchKernelGGL(k_allpairs_mfma<LIST>, dim3(ipanels_pad * splits), dim3(256), 0, stream,
-                       reinterpret_cast<const uint4*>(a->d_dense8), reinterpret_cast<const uint4*>(b->d_dense8),
+                       reinterpret_cast<const i32x4*>(a->d_dense8), reinterpret_cast<const i32x4*>(b->d_dense8),
                        n_ipanels, n_jpanels, n_chunks, splits, pps, (uint32_t)b->n_rows, (long long)excl, partial);
     SDRB_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_merge_topk<LIST>, dim3((uint32_t)((a->n_rows + 255) / 256)), dim3(256), 0, stream, partial,
@@ -355,3 +435,14 @@ int launch_allpairs_mfma(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, i
 }
 
 }  // namespace sdrb
+
+#ifdef SDRB_AP_EXP_STAMPS
+extern "C" int sdrb_debug_read_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sdrb::g_ap_stamps), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sdrb::g_ap_stamps), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
