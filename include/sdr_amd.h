@@ -56,6 +56,7 @@ extern "C" {
 #define SDRB_FLAG_FORCE_MERGE 2u    /* always use the general per-pair merge kernels */
 #define SDRB_FLAG_FORCE_BITSLICE 4u /* size ops: fail with UNSUPPORTED unless the bit-sliced kernel applies */
 #define SDRB_FLAG_FORCE_POPCOUNT 8u /* size ops: fail with UNSUPPORTED unless the dense-bitset popcount kernel applies */
+#define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;
 
@@ -146,8 +147,10 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
  * materialised.  When exclude_offset >= 0 the pair (i, j = i + exclude_offset) is skipped (the
  * self match when `a` is rows [exclude_offset, exclude_offset + na) of `b`).
  * out_counts / out_rows: device memory, [a rows][k]; unused slots hold count 0, row -1.
- * Kernel: dense int8 0/1 product on the matrix cores (v_mfma_i32_32x32x32_i8).  Needs declared
- * widths <= 16384, k <= 16 and rows shorter than 4096 ids on at least one side.
+ * Kernels (k <= 16, declared widths): a bit-sliced table kernel (widths <= 4096, rows of `a`
+ * <= 64 ids; the default when it applies, SDRB_FLAG_FORCE_BITSLICE insists on it) and a dense
+ * int8 0/1 product on the matrix cores, v_mfma_i32_32x32x32_i8 (widths <= 16384, rows shorter
+ * than 4096 ids on one side; SDRB_FLAG_FORCE_MFMA selects it).  Both give identical results.
  */
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream);

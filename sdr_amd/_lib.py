@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SDR_AMD_LIB") or os.path.join(_HERE, "libsdr_amd.so")
 OK = 0
 OP_AND, OP_OR, OP_XOR, OP_RM = 0, 1, 2, 3
 DATA_EMPTY, DATA_UNIT = 0, 1
-FLAG_SWAP, FLAG_FORCE_MERGE, FLAG_FORCE_BITSLICE, FLAG_FORCE_POPCOUNT = 1, 2, 4, 8
+FLAG_SWAP, FLAG_FORCE_MERGE, FLAG_FORCE_BITSLICE, FLAG_FORCE_POPCOUNT, FLAG_FORCE_MFMA = 1, 2, 4, 8, 16
 
 ERROR_NAMES = {
     -1: "SDRB_ERR_INVALID_ARG",

@@ -16,7 +16,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_POPCOUNT, FLAG_SWAP,
+from ._lib import (DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_SWAP,
                    OP_AND, OP_OR, OP_RM, OP_XOR, check)
 
 _KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT}
@@ -215,17 +215,19 @@ class SDRBatch:
                                      _stream_handle(other.device, stream)))
         return out
 
-    def allpairs_topk(self, other: "SDRBatch", k: int, *, exclude_offset: int = -1, stream=None):
+    def allpairs_topk(self, other: "SDRBatch", k: int, *, exclude_offset: int = -1, stream=None, algo=None):
         """For every row i of ``self``: the ``k`` rows j of ``other`` with the largest id overlap
         (``self[i].ands(other[j])`` on EmptyData views), overlap descending then j ascending.
         ``exclude_offset >= 0`` skips the pair (i, i + exclude_offset).  Returns
         ``(counts, rows)``: int32 ``[len(self), k]`` tensors on the device; unused slots are
-        (0, -1).  The full count matrix is never materialised."""
+        (0, -1).  The full count matrix is never materialised.  ``algo``: None (bit-sliced kernel
+        when it applies, else matrix cores), ``"bitslice"`` or ``"mfma"``."""
+        flags = {None: 0, "bitslice": FLAG_FORCE_BITSLICE, "mfma": FLAG_FORCE_MFMA}[algo]
         torch = _torch()
         dev = f"cuda:{other.device}"
         counts = torch.empty((max(self.n_rows, 1), k), dtype=torch.int32, device=dev)[: self.n_rows]
         rows = torch.empty((max(self.n_rows, 1), k), dtype=torch.int32, device=dev)[: self.n_rows]
-        check(self._lib.sdrb_allpairs_topk(self._h, other._h, k, exclude_offset, 0, counts.data_ptr(),
+        check(self._lib.sdrb_allpairs_topk(self._h, other._h, k, exclude_offset, flags, counts.data_ptr(),
                                            rows.data_ptr(), _stream_handle(other.device, stream)))
         return counts, rows
 

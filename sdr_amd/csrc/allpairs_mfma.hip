@@ -35,9 +35,9 @@ constexpr int kPanel = 256;          // rows per panel
 constexpr int kChunk = 64;           // ids per chunk
 constexpr int kPieceVec = 1024;      // 16-byte vectors per (panel, chunk) piece
 constexpr int kStageVec = 2048;      // vectors per operand per pipeline stage: two chunks of one panel
-constexpr int kKeyShift = 19;        // key = count << 19 | (2^19 - 1 - local j)
-constexpr int kLowMask = (1 << kKeyShift) - 1;
-constexpr uint32_t kMaxSplitRows = (uint32_t)kLowMask - 1;   // local j < 2^19 - 1 keeps keys > 0
+constexpr int kKeyShift = kTopkKeyShift;
+constexpr int kLowMask = kTopkLowMask;
+constexpr uint32_t kMaxSplitRows = kTopkMaxSplitRows;
 constexpr int kSubLists = 4;         // partial lists per (row i, j-split): 2 waves x 2 lane halves
 
 __host__ __device__ inline uint64_t dense_offset(uint64_t row, uint32_t id, uint32_t n_chunks) {
@@ -321,20 +321,19 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
 }
 
 // one thread per row i: k rounds of "largest key below the previous one" over all partial lists
-template <int LIST>
 __global__ __launch_bounds__(256) void k_merge_topk(const int* __restrict__ partial, uint32_t na, uint32_t splits,
-                                                    uint32_t panels_per_split, uint32_t k,
+                                                    uint32_t per_split, unsigned long long rows_per_split, uint32_t k,
                                                     uint32_t* __restrict__ out_counts, int32_t* __restrict__ out_rows) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= na) return;
-    const int* mine = partial + (uint64_t)i * splits * kSubLists * LIST;
+    const int* mine = partial + (uint64_t)i * splits * per_split;
     unsigned long long prev = ~0ull;
     for (uint32_t t = 0; t < k; ++t) {
         unsigned long long best = 0;
         for (uint32_t sp = 0; sp < splits; ++sp) {
-            const unsigned long long j_base = (unsigned long long)sp * panels_per_split * kPanel;
-            for (int e = 0; e < kSubLists * LIST; ++e) {
-                const int key = mine[sp * kSubLists * LIST + e];
+            const unsigned long long j_base = sp * rows_per_split;
+            for (uint32_t e = 0; e < per_split; ++e) {
+                const int key = mine[sp * per_split + e];
                 if (key <= 0) continue;
                 const unsigned long long count = (unsigned long long)(key >> kKeyShift);
                 const unsigned long long j = j_base + (unsigned long long)(kLowMask - (key & kLowMask));
@@ -411,13 +410,20 @@ int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint
                        reinterpret_cast<const i32x4*>(a->d_dense8), reinterpret_cast<const i32x4*>(b->d_dense8),
                        n_ipanels, n_jpanels, n_chunks, splits, pps, (uint32_t)b->n_rows, (long long)excl, partial);
     SDRB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_merge_topk<LIST>, dim3((uint32_t)((a->n_rows + 255) / 256)), dim3(256), 0, stream, partial,
-                       (uint32_t)a->n_rows, splits, pps, k, out_counts, out_rows);
-    SDRB_HIP(hipGetLastError());
-    return SDRB_OK;
+    return launch_merge_topk(partial, (uint32_t)a->n_rows, splits, kSubLists, (uint64_t)pps * kPanel, k, out_counts,
+                             out_rows, stream);
 }
 
 }  // namespace
+
+int launch_merge_topk(const int* partial, uint32_t na, uint32_t splits, uint32_t lists_per_split,
+                      uint64_t rows_per_split, uint32_t k, uint32_t* out_counts, int32_t* out_rows,
+                      hipStream_t stream) {
+    hipLaunchKernelGGL(k_merge_topk, dim3((na + 255) / 256), dim3(256), 0, stream, partial, na, splits,
+                       lists_per_split * kTopkList, (unsigned long long)rows_per_split, k, out_counts, out_rows);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
 
 bool allpairs_mfma_applicable(const sdrb_batch* a, const sdrb_batch* b, uint32_t k) {
     if (a->width <= 0 || b->width <= 0 || a->width > 16384 || b->width > 16384) return false;

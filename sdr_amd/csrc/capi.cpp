@@ -505,7 +505,6 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
 
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
-    (void)flags;
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc != SDRB_OK) return rc;
     if (k == 0 || !out_counts || !out_rows) {
@@ -513,8 +512,12 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
         return SDRB_ERR_INVALID_ARG;
     }
     if (a->n_rows == 0) return SDRB_OK;
-    if (!allpairs_mfma_applicable(a, b, k)) {
-        set_error("sdrb_allpairs_topk needs declared widths <= 16384, k <= 16 and rows shorter than 4096 ids");
+    const bool can_bitslice = allpairs_bitslice_applicable(a, b, k);
+    const bool can_mfma = allpairs_mfma_applicable(a, b, k);
+    const bool want_mfma = (flags & SDRB_FLAG_FORCE_MFMA) != 0, want_bitslice = (flags & SDRB_FLAG_FORCE_BITSLICE) != 0;
+    if ((want_mfma && !can_mfma) || (want_bitslice && !can_bitslice) || (!can_mfma && !can_bitslice)) {
+        set_error("sdrb_allpairs_topk: kernel not applicable (k <= 16 and declared widths needed; bit-sliced: "
+                  "widths <= 4096 and rows of a <= 64 ids; matrix-core: widths <= 16384 and rows shorter than 4096 ids)");
         return SDRB_ERR_UNSUPPORTED;
     }
     DeviceGuard guard(b->device);
@@ -522,7 +525,11 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
         set_error("hipSetDevice(%d) failed", b->device);
         return SDRB_ERR_HIP;
     }
-    return launch_allpairs_mfma(a, b, k, exclude_offset, out_counts, out_rows, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // at SDR densities the bit-sliced kernel does a fraction of the dense product's work
+    if (want_mfma || (!want_bitslice && !can_bitslice))
+        return launch_allpairs_mfma(a, b, k, exclude_offset, out_counts, out_rows, s);
+    return launch_allpairs_bitslice(a, b, k, exclude_offset, out_counts, out_rows, s);
 }
 
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,

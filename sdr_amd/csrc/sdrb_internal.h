@@ -81,11 +81,25 @@ bool popcount_applicable(const sdrb_batch* a, const sdrb_batch* b);
 int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                          uint32_t* out, uint64_t ld_out, hipStream_t stream);
 
-// allpairs_mfma.hip / allpairs_topk ----------------------------------------------------
+// allpairs_mfma.hip, allpairs_bitslice.hip ------------------------------------------------
 // For every row i of a: the k rows j of b with the largest id overlap (count desc, row asc).
+// Both kernels keep candidates as packed keys  count << 19 | (2^19 - 1 - local j)  (0 = empty,
+// so a valid key is > 0), in sorted lists of kTopkList entries; the rows of b are cut into
+// `splits` contiguous ranges of at most kTopkMaxSplitRows rows so that local j fits the key.
+constexpr int kTopkList = 16;
+constexpr int kTopkKeyShift = 19;
+constexpr int kTopkLowMask = (1 << kTopkKeyShift) - 1;
+constexpr uint32_t kTopkMaxSplitRows = (uint32_t)kTopkLowMask - 1;
 bool allpairs_mfma_applicable(const sdrb_batch* a, const sdrb_batch* b, uint32_t k);
 int launch_allpairs_mfma(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                          uint32_t* out_counts, int32_t* out_rows, hipStream_t stream);
+bool allpairs_bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b, uint32_t k);
+int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
+                             uint32_t* out_counts, int32_t* out_rows, hipStream_t stream);
+// partial: [row i][split][list][kTopkList] keys -> the best k per row (count, row), (0, -1) padded
+int launch_merge_topk(const int* partial, uint32_t na, uint32_t splits, uint32_t lists_per_split,
+                      uint64_t rows_per_split, uint32_t k, uint32_t* out_counts, int32_t* out_rows,
+                      hipStream_t stream);
 
 // unit_table.hip --------------------------------------------------------------------
 // Wave-per-row kernels with an LDS position table of one row of A (declared width <= 32768).

@@ -17,108 +17,11 @@
 // (4 bytes per pair) is the only large stream, so the kernel is bound by HBM write bandwidth.
 #include <type_traits>
 
-#include "sdrb_internal.h"
+#include "bitslice_device.h"
 
 namespace sdrb {
 
 namespace {
-
-using u64 = unsigned long long;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// tuning constants (overridable at build time for experiments)
-#ifndef SDRB_BS_BLOCK
-#define SDRB_BS_BLOCK 256
-#endif
-#ifndef SDRB_BS_MIN_WAVES
-#define SDRB_BS_MIN_WAVES 3
-#endif
-constexpr int kBlock = SDRB_BS_BLOCK;  // threads per block = rows of B per block
-constexpr int kMinWaves = SDRB_BS_MIN_WAVES;  // waves per SIMD the register allocator must allow
-constexpr int kTileRows = 64;  // rows of A per table tile = bits of one table word
-
-__global__ __launch_bounds__(64) void k_build_table(const uint32_t* __restrict__ a_off,
-                                                     const int32_t* __restrict__ a_ids,
-                                                     int32_t width, uint32_t tile_words,
-                                                     u64* __restrict__ table,
-                                                     uint32_t* __restrict__ a_len) {
-    const uint64_t i = blockIdx.x;
-    const uint32_t beg = a_off[i];
-    const uint32_t len = a_off[i + 1] - beg;
-    if (threadIdx.x == 0) a_len[i] = len;
-    u64* tile = table + (i / kTileRows) * (uint64_t)tile_words;
-    const u64 bit = 1ull << (i % kTileRows);
-    for (uint32_t k = threadIdx.x; k < len; k += 64) {
-        const int32_t id = a_ids[beg + k];
-        // ids outside B's declared width cannot match any id of B
-        if ((uint32_t)id < (uint32_t)width) atomicOr(&tile[id], bit);
-    }
-}
-
-constexpr int bits_for(int n) {  // bits needed to hold values 0..n
-    int b = 0;
-    while (n > 0) { ++b; n >>= 1; }
-    return b;
-}
-
-// full adder over 32 independent 1-bit columns: carry = majority, sum = parity
-__device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b, uint32_t c) {
-    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
-    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-}
-__device__ __forceinline__ void half_add(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b) {
-    carry = a & b;
-    sum = a ^ b;
-}
-
-__device__ __forceinline__ uint32_t rotr32(uint32_t x, int s) {
-    return __builtin_amdgcn_alignbit(x, x, (uint32_t)(s & 31));
-}
-
-// Adds eight 32-column bit words into the vertical counter P (Harley-Seal step):
-// P[0..2] keep count mod 8, the weight-8 carry ripples into P[3..].
-template <int NPL, bool FIRST>
-__device__ __forceinline__ void add8(uint32_t (&P)[NPL], const uint32_t (&x)[8]) {
-    uint32_t t2a, t2b, t4a, t4b, e8;
-    if constexpr (FIRST) {  // P is all zero
-        half_add(t2a, P[0], x[0], x[1]);
-        csa(t2b, P[0], P[0], x[2], x[3]);
-        half_add(t4a, P[1], t2a, t2b);
-        csa(t2a, P[0], P[0], x[4], x[5]);
-        csa(t2b, P[0], P[0], x[6], x[7]);
-        csa(t4b, P[1], P[1], t2a, t2b);
-        half_add(e8, P[2], t4a, t4b);
-        if constexpr (NPL > 3) P[3] = e8;
-    } else {
-        csa(t2a, P[0], P[0], x[0], x[1]);
-        csa(t2b, P[0], P[0], x[2], x[3]);
-        csa(t4a, P[1], P[1], t2a, t2b);
-        csa(t2a, P[0], P[0], x[4], x[5]);
-        csa(t2b, P[0], P[0], x[6], x[7]);
-        csa(t4b, P[1], P[1], t2a, t2b);
-        csa(e8, P[2], P[2], t4a, t4b);
-#pragma unroll
-        for (int p = 3; p < NPL; ++p) {
-            const uint32_t nc = P[p] & e8;
-            P[p] ^= e8;
-            e8 = nc;
-        }
-    }
-}
-
-template <int PF>
-__device__ __forceinline__ void load_tile(u32x4 (&pf)[PF], const u64* __restrict__ tile, uint32_t tid) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(tile);
-#pragma unroll
-    for (int p = 0; p < PF; ++p) pf[p] = src[tid + p * kBlock];
-}
-
-template <int PF>
-__device__ __forceinline__ void write_tile(const u32x4 (&pf)[PF], u64* buf, uint32_t tid) {
-    u32x4* dst = reinterpret_cast<u32x4*>(buf);
-#pragma unroll
-    for (int p = 0; p < PF; ++p) dst[tid + p * kBlock] = pf[p];
-}
 
 // One tile: gather the row's table words from LDS buffer `buf`, count, unpack, store.
 // `rows_in_tile` < 64 only for the last tile of A; stores to the missing rows are switched

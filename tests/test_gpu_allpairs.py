@@ -35,17 +35,21 @@ def expected_topk(counts, k, exclude_offset):
     return want_c, want_r
 
 
-def run_case(a_csr, b_csr, width, k, exclude_offset):
+ALGOS = ["mfma", "bitslice"]
+
+
+def run_case(a_csr, b_csr, width, k, exclude_offset, algos=ALGOS):
     import oracle
     from sdr_amd import SDRBatch
     a = SDRBatch.from_csr(*a_csr, width=width)
     b = SDRBatch.from_csr(*b_csr, width=width)
-    got_c, got_r = a.allpairs_topk(b, k, exclude_offset=exclude_offset)
     counts = oracle.port().size_op(oracle.AND, oracle.Batch(a_csr[0], a_csr[1], None),
                                    oracle.Batch(b_csr[0], b_csr[1], None))
     want_c, want_r = expected_topk(counts, k, exclude_offset)
-    assert np.array_equal(got_r.cpu().numpy(), want_r)
-    assert np.array_equal(got_c.cpu().numpy(), want_c)
+    for algo in algos:
+        got_c, got_r = a.allpairs_topk(b, k, exclude_offset=exclude_offset, algo=algo)
+        assert np.array_equal(got_r.cpu().numpy(), want_r), algo
+        assert np.array_equal(got_c.cpu().numpy(), want_c), algo
 
 
 @pytest.mark.parametrize("na,nb,width,active,k,excl", [
@@ -54,7 +58,8 @@ def run_case(a_csr, b_csr, width, k, exclude_offset):
     (700, 700, 2048, 40, 5, 0),         # self all-pairs, self match excluded
     (130, 900, 300, 60, 16, 200),       # a = rows 200.. of b, width not a multiple of 64
     (40, 9, 2048, 40, 16, -1),          # fewer candidates than k
-    (64, 3000, 4096, 100, 1, -1),       # k = 1, long rows
+    (64, 3000, 4096, 64, 1, -1),        # k = 1, width 4096, rows up to 64 ids
+    (1000, 70, 100, 30, 3, -1),         # one candidate tile and a bit, short lists
 ])
 def test_allpairs_topk_vs_oracle(na, nb, width, active, k, excl):
     rng = np.random.default_rng(na * 7919 + nb)
@@ -66,6 +71,20 @@ def test_allpairs_topk_vs_oracle(na, nb, width, active, k, excl):
     else:
         a_csr = util.ragged_rows(rng, na, width, active, False)
     run_case(a_csr, b_csr, width, k, excl)
+
+
+def test_allpairs_topk_long_rows_need_the_matrix_cores():
+    """Rows longer than 64 ids do not fit the bit-sliced kernel's registers: the default falls
+    back to the matrix-core kernel and forcing the bit-sliced one is refused."""
+    from sdr_amd import SDRBatch, SdrbError
+    rng = np.random.default_rng(8)
+    a_csr = util.ragged_rows(rng, 70, 4096, 300, False)
+    b_csr = util.ragged_rows(rng, 900, 4096, 300, False)
+    run_case(a_csr, b_csr, 4096, 16, -1, algos=[None, "mfma"])
+    a = SDRBatch.from_csr(*a_csr, width=4096)
+    b = SDRBatch.from_csr(*b_csr, width=4096)
+    with pytest.raises(SdrbError):
+        a.allpairs_topk(b, 16, algo="bitslice")
 
 
 def test_allpairs_topk_many_ties_and_duplicates():

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check-rows", type=int, default=4)
+    ap.add_argument("--algo", default=None, choices=[None, "mfma", "bitslice"])
     args = ap.parse_args()
 
     import torch
@@ -40,13 +41,13 @@ def main():
     b = SDRBatch.from_csr(off, ids, None, width=args.width)
     a_off = off[: args.na + 1].copy()
     a = SDRBatch.from_csr(a_off, ids[: int(a_off[-1])], None, width=args.width)
-    a.allpairs_topk(b, args.k, exclude_offset=0)      # builds the byte matrices, warms up
+    a.allpairs_topk(b, args.k, exclude_offset=0, algo=args.algo)      # builds the byte matrices, warms up
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        counts, rows = a.allpairs_topk(b, args.k, exclude_offset=0)
+        counts, rows = a.allpairs_topk(b, args.k, exclude_offset=0, algo=args.algo)
     ev1.record()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / args.steps
@@ -71,7 +72,7 @@ def main():
     print(json.dumps({
         "workload": f"all-pairs overlap + top-{args.k}: {args.na} x {args.nb} rows, width {args.width}, "
                     f"{args.active} active, self match excluded",
-        "ms": dev * 1e3, "wall_ms": wall * 1e3,
+        "algo": args.algo or "default", "ms": dev * 1e3, "wall_ms": wall * 1e3,
         "pair_ops_per_s": args.na * args.nb / dev,
         "int8_ops_per_s": ops / dev, "mfma_peak_ops_per_s": I8_PEAK_OPS, "mfma_frac": ops / dev / I8_PEAK_OPS,
         "parity_checked": bool(ok) if ok is not None else None,
