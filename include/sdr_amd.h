@@ -117,6 +117,14 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
 /* Smallest and largest id over all rows (min_id > max_id for a batch without elements). */
 int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id);
 
+/*
+ * Copies the packed CSR into caller buffers on the same device (device-to-device, ordered on
+ * `stream`): row_offsets[n_rows+1], ids[nnz], data[nnz] (UnitData batches; may be NULL otherwise).
+ * This is the sending side of an exchange whose receiving side is sdrb_batch_adopt_device_csr.
+ */
+int sdrb_batch_export_device_csr(const sdrb_batch* batch, uint32_t* row_offsets, int32_t* ids, float* data,
+                                 void* stream);
+
 /* Device pointers of the packed CSR (read-only views, valid until the next upload/destroy). */
 int sdrb_batch_device_ptrs(const sdrb_batch* batch, const uint32_t** row_offsets,
                            const int32_t** ids, const float** data);

@@ -57,6 +57,9 @@ class Batch:
             off.append(len(ids))
         return cls(off, ids, data if with_data else None)
 
+    def csr(self):
+        return self.off, self.ids, self.data
+
     def args(self):
         return [self.off.ctypes.data_as(_vp), self.ids.ctypes.data_as(_vp),
                 self.data.ctypes.data_as(_vp) if self.data is not None else None, self.kind, self.n]

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "sdrb_batch_info": (C.c_int, [_vp, C.POINTER(C.c_int), _u64p, _u64p, _i32p, C.POINTER(C.c_int), _u32p]),
     "sdrb_batch_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sdrb_batch_destroy": (C.c_int, [_vp]),
+    "sdrb_batch_export_device_csr": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sdrb_size_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_allpairs_topk": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int64, C.c_uint, _vp, _vp, _vp]),
     "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),

@@ -168,6 +168,21 @@ class SDRBatch:
         self._views = (offsets, ids, data)
         self.n_rows, self.nnz, self.max_row_len = n_rows, nnz, int(max_row_len)
 
+    def to_wire(self, stream=None):
+        """The batch in wire form: one int32 device tensor ``[offsets (n_rows+1) | ids (nnz) |
+        payload bits (nnz, UnitData only)]`` (a device-to-device copy), the sending side of
+        :meth:`adopt_device`."""
+        torch = _torch()
+        unit = self.data_kind == DATA_UNIT
+        words = self.n_rows + 1 + self.nnz * (2 if unit else 1)
+        wire = torch.empty(words, dtype=torch.int32, device=f"cuda:{self.device}")
+        ids_t = wire[self.n_rows + 1: self.n_rows + 1 + self.nnz]
+        data_t = wire[self.n_rows + 1 + self.nnz:]
+        check(self._lib.sdrb_batch_export_device_csr(
+            self._h, wire.data_ptr(), ids_t.data_ptr() if self.nnz else None,
+            data_t.data_ptr() if (unit and self.nnz) else None, _stream_handle(self.device, stream)))
+        return wire
+
     def stats(self) -> dict:
         """Shape and id statistics of the uploaded batch (what a zero-copy view needs)."""
         lo, hi = C.c_int32(), C.c_int32()

@@ -442,6 +442,25 @@ int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id
     return SDRB_OK;
 }
 
+int sdrb_batch_export_device_csr(const sdrb_batch* batch, uint32_t* row_offsets, int32_t* ids, float* data,
+                                 void* stream) {
+    if (!batch || !batch->d_offsets || !row_offsets || (batch->nnz && !ids) ||
+        (batch->nnz && batch->data_kind == SDRB_DATA_UNIT && !data)) {
+        set_error("sdrb_batch_export_device_csr: null argument or empty handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(batch->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SDRB_HIP(hipMemcpyAsync(row_offsets, batch->d_offsets, (batch->n_rows + 1) * sizeof(uint32_t),
+                            hipMemcpyDeviceToDevice, s));
+    if (batch->nnz) {
+        SDRB_HIP(hipMemcpyAsync(ids, batch->d_ids, batch->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (batch->data_kind == SDRB_DATA_UNIT)
+            SDRB_HIP(hipMemcpyAsync(data, batch->d_data, batch->nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return SDRB_OK;
+}
+
 int sdrb_batch_device_ptrs(const sdrb_batch* batch, const uint32_t** row_offsets,
                            const int32_t** ids, const float** data) {
     if (!batch) {

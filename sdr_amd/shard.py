@@ -119,8 +119,17 @@ class HipEngine:
                        max_row_len=plan.max_row_len, min_id=plan.min_id, max_id=plan.max_id)
         return b
 
+    def to_wire(self, batch):
+        """(wire tensor, plan) of a batch that lives on this engine's device."""
+        st = batch.stats()
+        plan = QueryPlan(st["n_rows"], st["nnz"], bool(st["has_data"]), st["max_row_len"], st["min_id"], st["max_id"])
+        return batch.to_wire(), plan
+
     def size_op(self, name: str, queries, shard, out=None):
         return getattr(queries, name)(shard, out=out)
+
+    def allpairs_topk(self, rows, candidates, k, exclude_offset):
+        return rows.allpairs_topk(candidates, k, exclude_offset=exclude_offset)
 
 
 class ShardedDatabase:
@@ -203,6 +212,63 @@ class ShardedDatabase:
         if world > 1 or (force_collective and on):
             dist.broadcast(tensor, src=src, group=self.group)
         return self.engine.adopt(tensor, plan, self.width, into=into)
+
+    # -- all-pairs: every rank needs every row as a candidate ---------------------------------
+    def gather_database(self):
+        """All-gathers the shards' CSR (wire form, padded to the largest shard; 164 B per 40-id
+        row) and returns a batch that holds the WHOLE database in global row order on this rank.
+        Two collectives: the shards' plans (six integers each), then the wire tensors."""
+        import torch
+        import torch.distributed as dist
+
+        wire, plan = self.engine.to_wire(self.shard)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return self.engine.adopt(wire, plan, self.width)
+        dev = self.engine.torch_device()
+        mine = torch.tensor([plan.n_rows, plan.nnz, int(plan.has_data), plan.max_row_len, plan.min_id, plan.max_id],
+                            dtype=torch.int64, device=dev)
+        plans_t = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(plans_t, mine, group=self.group)
+        plans = [QueryPlan(*(int(x) for x in t.tolist()[:2]), bool(int(t[2])), *(int(x) for x in t.tolist()[3:]))
+                 for t in plans_t]
+        if len({p.has_data for p in plans}) != 1:
+            raise ValueError("shards disagree on the payload kind")
+        words = max(p.words for p in plans)
+        padded = torch.zeros(words, dtype=torch.int32, device=dev)
+        padded[: wire.numel()] = wire
+        wires = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(wires, padded, group=self.group)
+        # stitch: offsets rebased by the elements of the shards before, then ids, then payloads
+        offs, ids, datas, base = [], [], [], 0
+        for p, w in zip(plans, wires):
+            o = w[: p.n_rows + 1].to(torch.int64) + base
+            offs.append(o if not offs else o[1:])
+            ids.append(w[p.n_rows + 1: p.n_rows + 1 + p.nnz])
+            if p.has_data:
+                datas.append(w[p.n_rows + 1 + p.nnz: p.n_rows + 1 + 2 * p.nnz])
+            base += p.nnz
+        if base > 0xFFFFFFFF:
+            raise OverflowError("the gathered database exceeds 2^32-1 elements")
+        # (offsets travel as the low 32 bits; the batch reads them as uint32)
+        off_all = torch.cat(offs)
+        off_all = torch.where(off_all >= 2 ** 31, off_all - 2 ** 32, off_all).to(torch.int32)
+        whole = torch.cat([off_all] + ids + datas)
+        with_elems = [p for p in plans if p.nnz]
+        total = QueryPlan(sum(p.n_rows for p in plans), base, plans[0].has_data,
+                          max(p.max_row_len for p in plans),
+                          min((p.min_id for p in with_elems), default=0),
+                          max((p.max_id for p in with_elems), default=-1))
+        return self.engine.adopt(whole, total, self.width)
+
+    def allpairs_topk(self, k: int, exclude_self: bool = True, candidates=None):
+        """For every row of this rank's shard: the k rows of the WHOLE database with the largest id
+        overlap, as (counts, global rows), overlap descending then row ascending.  The shards'
+        rows are disjoint, so results need no merge; ``candidates`` (from :meth:`gather_database`)
+        can be reused across calls."""
+        if candidates is None:
+            candidates = self.gather_database()
+        return self.engine.allpairs_topk(self.shard, candidates, k, self.row_lo if exclude_self else -1)
 
     def _pack(self, off_t, ids_t, data_t, into):
         if into is not None:

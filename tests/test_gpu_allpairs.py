@@ -114,3 +114,19 @@ def test_allpairs_topk_ignores_payloads_and_reuses_dense_cache():
     c4, r4 = empty.allpairs_topk(empty, 8, exclude_offset=0)
     c5, r5 = fresh.allpairs_topk(fresh, 8, exclude_offset=0)
     assert torch.equal(c4, c5) and torch.equal(r4, r5)
+
+
+def test_sharded_driver_allpairs_single_rank():
+    """The shard driver's all-pairs path on one GPU: the shard is exported to wire form, adopted
+    as the candidate batch, and every row's self match is excluded by the shard's row offset."""
+    import oracle
+    from sdr_amd.shard import HipEngine, ShardedDatabase
+    rng = np.random.default_rng(21)
+    off, ids, data = util.ragged_rows(rng, 900, 2048, 40, True)     # payloads travel too, and are ignored
+    db = ShardedDatabase.from_global_csr(off, ids, data, width=2048, engine=HipEngine(0), rank=0, world=1)
+    whole = db.gather_database()
+    assert whole.stats() == db.shard.stats()
+    got_c, got_r = db.allpairs_topk(16, candidates=whole)
+    counts = oracle.port().size_op(oracle.AND, oracle.Batch(off, ids, None), oracle.Batch(off, ids, None))
+    want_c, want_r = expected_topk(counts, 16, 0)
+    assert np.array_equal(got_r.cpu().numpy(), want_r) and np.array_equal(got_c.cpu().numpy(), want_c)

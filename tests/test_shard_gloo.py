@@ -43,6 +43,25 @@ class OracleEngine:
         data_t = tensor[nq + 1 + nnz:].view(torch.float32) if plan.has_data else None
         return self.pack_device(tensor[: nq + 1], tensor[nq + 1: nq + 1 + nnz], data_t, width)
 
+    def to_wire(self, batch):
+        off, ids, data = batch.csr()
+        wire = PackedQueries.from_host_csr(off, ids, data, width=0, engine=self)
+        return wire.tensor, wire.plan
+
+    def allpairs_topk(self, rows, candidates, k, exclude_offset):
+        import oracle
+        counts = oracle.port().size_op(0, oracle.Batch(rows.csr()[0], rows.csr()[1], None),
+                                       oracle.Batch(candidates.csr()[0], candidates.csr()[1], None)).astype(np.int64)
+        out_c = np.zeros((counts.shape[0], k), np.int64)
+        out_r = np.full((counts.shape[0], k), -1, np.int64)
+        for i in range(counts.shape[0]):
+            cand = np.arange(counts.shape[1])
+            if exclude_offset >= 0:
+                cand = cand[cand != i + exclude_offset]
+            order = cand[np.lexsort((cand, -counts[i][cand]))][:k]
+            out_c[i, : len(order)], out_r[i, : len(order)] = counts[i][order], order
+        return torch.from_numpy(out_c), torch.from_numpy(out_r)
+
     def size_op(self, name, queries, shard, out=None):
         import oracle
         return torch.from_numpy(oracle.port().size_op(OPS[name], queries, shard).astype(np.int32))
@@ -81,6 +100,14 @@ def _worker(rank, world, port, with_data, n_rows, results):
         assert wire.plan.words == wire.tensor.numel()
         again = db.broadcast_packed(wire if rank == 0 else None, wire.plan, src=0)
         assert np.array_equal(db.gather_counts(db.size_op("xors", again)).numpy(), out["xors"])
+        # all-pairs: the shards are all-gathered into the whole database on every rank
+        whole = db.gather_database()
+        w_off, w_ids, w_data = whole.csr()
+        assert np.array_equal(w_off, d_off) and np.array_equal(w_ids, d_ids)
+        assert (w_data is None) == (d_data is None) and (w_data is None or np.array_equal(w_data, d_data))
+        ap_c, ap_r = db.allpairs_topk(4, candidates=whole)
+        out[f"allpairs_{rank}"] = (db.row_lo, ap_c.numpy(), ap_r.numpy())
+        results[f"allpairs_{rank}"] = out[f"allpairs_{rank}"]
         counts, rows = db.topk(db.size_op("ands", queries), 5)
         out["topk_counts"], out["topk_rows"] = counts.numpy(), rows.numpy()
         if rank == 0:
@@ -105,6 +132,16 @@ def test_two_rank_sharded_size_ops(with_data, n_rows):
         want = oracle.port().size_op(op, q, d)
         assert np.array_equal(results[name].view(np.uint32), want), name
     assert np.array_equal(results["rank1_ands"], results["ands"])
+    # all-pairs top-4 of every row over the whole database, self match excluded
+    self_counts = oracle.port().size_op(0, oracle.Batch(d.csr()[0], d.csr()[1], None),
+                                        oracle.Batch(d.csr()[0], d.csr()[1], None)).astype(np.int64)
+    for rank in range(world):
+        lo, got_c, got_r = results[f"allpairs_{rank}"]
+        for n in range(got_r.shape[0]):
+            i = lo + n
+            cand = [r for r in range(n_rows) if r != i]
+            order = sorted(cand, key=lambda r: (-self_counts[i, r], r))[:4]
+            assert got_r[n].tolist() == order and got_c[n].tolist() == [int(self_counts[i, r]) for r in order]
     # top-k: count descending, ties to the lower row index
     want = oracle.port().size_op(0, q, d).astype(np.int64)
     for i in range(9):
