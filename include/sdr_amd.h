@@ -40,6 +40,8 @@ extern "C" {
 #define SDRB_ERR_UNSUPPORTED (-5)
 #define SDRB_ERR_OVERFLOW (-6)      /* more than 2^32-1 elements in one batch or one result */
 #define SDRB_ERR_PAYLOAD_RANGE (-7) /* a UnitData payload outside [0,1] (UnitData.hpp:15-17) */
+#define SDRB_ERR_IO (-8)            /* a file could not be opened, read or written */
+#define SDRB_ERR_FORMAT (-9)        /* not a CSR database file, or its tables are inconsistent */
 
 /* set operations */
 #define SDRB_OP_AND 0
@@ -59,6 +61,7 @@ extern "C" {
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;
+typedef struct sdrb_file_writer sdrb_file_writer;
 
 /* Message of the calling thread's most recent failure ("" if none). */
 const char* sdrb_last_error(void);
@@ -193,6 +196,34 @@ int sdrb_free(int device, void* ptr);
 int sdrb_memcpy_h2d(int device, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int sdrb_memcpy_d2h(int device, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int sdrb_stream_sync(int device, void* stream);
+
+/*
+ * CSR database files (host side; no GPU needed except for sdrb_batch_upload_file).  The reference
+ * has no serialisation (SDR.hpp:1670-1680 prints text only); the container is this engine's own:
+ * a 64-byte header {magic "SDRBCSR1", version, payload flag, id bits, width, rows, elements,
+ * section positions} followed by 64-byte aligned sections int32 ids[], float data[] (UnitData
+ * only) and uint64 row_offsets[rows+1], little endian, mmap-able.
+ *
+ * Writer: rows are appended in chunks of any size (row_offsets relative to the chunk, first 0)
+ * and checked like an upload (ascending ids SDR.hpp:679,1621; declared width; payloads in [0,1]
+ * UnitData.hpp:15-17); close() finishes the file, abort() removes it.  A writer is freed by
+ * close or abort.
+ */
+int sdrb_file_writer_open(const char* path, int32_t width, int data_kind, sdrb_file_writer** out);
+int sdrb_file_writer_append(sdrb_file_writer* writer, uint64_t n_rows, const uint64_t* row_offsets,
+                            const int32_t* ids, const float* data);
+int sdrb_file_writer_close(sdrb_file_writer* writer);
+int sdrb_file_writer_abort(sdrb_file_writer* writer);
+
+/* Shape of a file; any out pointer may be NULL. */
+int sdrb_file_info(const char* path, uint64_t* n_rows, uint64_t* nnz, int32_t* width, int* data_kind);
+/* Elements held by rows [row_lo, row_hi). */
+int sdrb_file_row_span(const char* path, uint64_t row_lo, uint64_t row_hi, uint64_t* nnz);
+/* Rows [row_lo, row_hi) into caller arrays: row_offsets[row_hi-row_lo+1] rebased to 0, ids, data (may be NULL). */
+int sdrb_file_read_rows(const char* path, uint64_t row_lo, uint64_t row_hi, uint64_t* row_offsets,
+                        int32_t* ids, float* data);
+/* Uploads rows [row_lo, row_hi) of a file into a batch straight from the mapping (a shard of a database file). */
+int sdrb_batch_upload_file(sdrb_batch* batch, const char* path, uint64_t row_lo, uint64_t row_hi, void* stream);
 
 /*
  * Deterministic synthetic rows for the bench/verify harness (no reference counterpart;

@@ -86,6 +86,68 @@ struct DeviceBuffer {
 
 }  // namespace detail
 
+// Streams the SDRs of [first, last) into a CSR database file, `chunk_rows` at a time (the reference
+// has no serialisation, SDR.hpp:1670-1680 prints text only).  Rows are read by iteration, so any
+// container works; payloads with a float value() are stored.
+template <typename Iter>
+void save(Iter first, Iter last, const std::string& path, int32_t width = 0, size_t chunk_rows = 65536) {
+    using SDR_t = std::decay_t<decltype(*first)>;
+    constexpr bool unit = detail::has_value<detail::data_of<SDR_t>>::value;
+    sdrb_file_writer* w = nullptr;
+    check(sdrb_file_writer_open(path.c_str(), width, unit ? SDRB_DATA_UNIT : SDRB_DATA_EMPTY, &w));
+    std::vector<uint64_t> off;
+    std::vector<int32_t> ids;
+    std::vector<float> data;
+    auto flush = [&]() {
+        const int rc = sdrb_file_writer_append(w, off.size() - 1, off.data(), ids.data(), unit ? data.data() : nullptr);
+        if (rc != SDRB_OK) {
+            const std::string msg = sdrb_last_error();
+            sdrb_file_writer_abort(w);
+            throw Error(rc, msg);
+        }
+    };
+    while (first != last) {
+        off.assign(1, 0);
+        ids.clear();
+        data.clear();
+        for (size_t n = 0; n < chunk_rows && first != last; ++n, ++first) {
+            for (auto it = first->cbegin(); it != first->cend(); ++it) {
+                ids.push_back(static_cast<int32_t>(it->id()));
+                if constexpr (unit) data.push_back(static_cast<float>(it->data().value()));
+            }
+            off.push_back(ids.size());
+        }
+        flush();
+    }
+    check(sdrb_file_writer_close(w));
+}
+
+// Rows [row_lo, row_hi) of a CSR database file as SDR objects of the caller's type (row_hi = 0: to the end).
+template <typename SDR_t>
+std::vector<SDR_t> load_rows(const std::string& path, uint64_t row_lo = 0, uint64_t row_hi = 0) {
+    using Elem = detail::elem_of<SDR_t>;
+    using Data = detail::data_of<SDR_t>;
+    uint64_t n_rows = 0, span = 0;
+    int kind = SDRB_DATA_EMPTY;
+    check(sdrb_file_info(path.c_str(), &n_rows, nullptr, nullptr, &kind));
+    if (row_hi == 0) row_hi = n_rows;
+    check(sdrb_file_row_span(path.c_str(), row_lo, row_hi, &span));
+    std::vector<uint64_t> off(row_hi - row_lo + 1);
+    std::vector<int32_t> ids(span ? span : 1);
+    std::vector<float> data(kind == SDRB_DATA_UNIT ? (span ? span : 1) : 0);
+    check(sdrb_file_read_rows(path.c_str(), row_lo, row_hi, off.data(), ids.data(), data.empty() ? nullptr : data.data()));
+    std::vector<SDR_t> rows(row_hi - row_lo);
+    for (size_t r = 0; r < rows.size(); ++r)
+        for (uint64_t k = off[r]; k < off[r + 1]; ++k) {
+            if constexpr (detail::has_value<Data>::value) {
+                rows[r].push_back(data.empty() ? Elem(ids[k]) : Elem(ids[k], Data(data[k])));
+            } else {
+                rows[r].push_back(Elem(ids[k]));
+            }
+        }
+    return rows;
+}
+
 // uint32 counts[na][nb] in device memory
 class Counts {
  public:
@@ -98,6 +160,24 @@ class Counts {
  private:
     size_t na_, nb_;
     detail::DeviceBuffer buf_;
+};
+
+// Per row of the left batch: the k rows of the right batch with the largest id overlap
+// (overlap descending, then row ascending; unused slots hold count 0, row -1)
+class TopK {
+ public:
+    TopK(int device, size_t na, size_t k)
+        : na_(na), k_(k), counts_(device, (na * k ? na * k : 1) * sizeof(uint32_t)), rows_(device, (na * k ? na * k : 1) * sizeof(int32_t)) {}
+    size_t rows() const { return na_; }
+    size_t k() const { return k_; }
+    uint32_t* counts_ptr() const { return static_cast<uint32_t*>(counts_.ptr); }
+    int32_t* rows_ptr() const { return static_cast<int32_t*>(rows_.ptr); }
+    std::vector<uint32_t> counts_to_host(void* stream = nullptr) const { return counts_.to_host<uint32_t>(na_ * k_, stream); }
+    std::vector<int32_t> rows_to_host(void* stream = nullptr) const { return rows_.to_host<int32_t>(na_ * k_, stream); }
+
+ private:
+    size_t na_, k_;
+    detail::DeviceBuffer counts_, rows_;
 };
 
 // CSR result of an element op over all pairs
@@ -166,6 +246,20 @@ class SDRBatch {
         return b;
     }
 
+    // Rows [row_lo, row_hi) of a CSR database file (see save()) as a device batch; row_hi = 0: to the end.
+    static SDRBatch from_file(const std::string& path, int device = 0, uint64_t row_lo = 0, uint64_t row_hi = 0,
+                              void* stream = nullptr) {
+        uint64_t n_rows = 0;
+        int32_t width = 0;
+        int kind = SDRB_DATA_EMPTY;
+        check(sdrb_file_info(path.c_str(), &n_rows, nullptr, &width, &kind));
+        if (row_hi == 0) row_hi = n_rows;
+        SDRBatch b(device, width, kind);
+        check(sdrb_batch_upload_file(b.h_, path.c_str(), row_lo, row_hi, stream));
+        b.n_rows_ = row_hi - row_lo;
+        return b;
+    }
+
     void upload(const std::vector<uint64_t>& off, const std::vector<int32_t>& ids,
                 const std::vector<float>& data, void* stream = nullptr) {
         check(sdrb_batch_upload_csr(h_, off.size() - 1, off.data(), ids.data(),
@@ -182,6 +276,16 @@ class SDRBatch {
     Counts ors(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_OR, db, flags, stream); }
     Counts xors(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_XOR, db, flags, stream); }
     Counts rms(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_RM, db, flags, stream); }
+
+    // For every row i: the k rows j of db with the largest |(*this)[i] ∩ db[j]| -- the value ands returns
+    // on id-only elements (SDR.hpp:1083-1095); pair (i, i + exclude_offset) is skipped when exclude_offset >= 0.
+    // The reference has no top-k: ties go to the lower row.
+    TopK allpairs_topk(const SDRBatch& db, uint32_t k, int64_t exclude_offset = -1, unsigned flags = 0,
+                       void* stream = nullptr) const {
+        TopK t(db.device_, n_rows_, k);
+        check(sdrb_allpairs_topk(h_, db.h_, k, exclude_offset, flags, t.counts_ptr(), t.rows_ptr(), stream));
+        return t;
+    }
 
     // (*this)[i].ande(db[j]) ... as CSR (SDR.hpp:151-152,209-212,237-240,292-293)
     Elements ande(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_AND, db, flags, stream); }

@@ -24,6 +24,8 @@ ERROR_NAMES = {
     -5: "SDRB_ERR_UNSUPPORTED",
     -6: "SDRB_ERR_OVERFLOW",
     -7: "SDRB_ERR_PAYLOAD_RANGE",
+    -8: "SDRB_ERR_IO",
+    -9: "SDRB_ERR_FORMAT",
 }
 
 
@@ -51,6 +53,15 @@ PROTOTYPES = {
     "sdrb_batch_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sdrb_batch_destroy": (C.c_int, [_vp]),
     "sdrb_batch_export_device_csr": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sdrb_file_writer_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int, C.POINTER(_vp)]),
+    "sdrb_file_writer_append": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp]),
+    "sdrb_file_writer_close": (C.c_int, [_vp]),
+    "sdrb_file_writer_abort": (C.c_int, [_vp]),
+    "sdrb_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int)]),
+    "sdrb_file_row_span": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "sdrb_file_read_rows": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    "sdrb_batch_upload_file": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_uint64, _vp]),
     "sdrb_size_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_allpairs_topk": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int64, C.c_uint, _vp, _vp, _vp]),
     "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),

@@ -125,6 +125,12 @@ class SDRBatch:
         check(self._lib.sdrb_batch_info(self._h, None, None, None, None, None, C.byref(mx)))
         self.max_row_len = int(mx.value)
 
+    def _refresh_info(self) -> None:
+        """Re-reads rows / elements / longest row from the handle (after an upload done in C)."""
+        n, nnz, mx = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        check(self._lib.sdrb_batch_info(self._h, None, C.byref(n), C.byref(nnz), None, None, C.byref(mx)))
+        self.n_rows, self.nnz, self.max_row_len = int(n.value), int(nnz.value), int(mx.value)
+
     def upload_device(self, offsets, ids, data=None, *, stream=None) -> None:
         """Packs a CSR that already lives on this device: ``offsets`` int32 tensor [n_rows+1]
         (uint32 values), ``ids`` int32 tensor, ``data`` float32 tensor for UnitData batches."""

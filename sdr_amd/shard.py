@@ -94,6 +94,10 @@ class HipEngine:
         from .batch import SDRBatch
         return SDRBatch.from_csr(off, ids, data, width=width, device=self.device)
 
+    def pack_file(self, path, row_lo, row_hi):
+        from . import csrfile
+        return csrfile.upload_rows(path, row_lo, row_hi, device=self.device)
+
     def pack_device(self, off_t, ids_t, data_t, width, into=None):
         from .batch import SDRBatch
         from ._lib import DATA_EMPTY, DATA_UNIT
@@ -151,6 +155,15 @@ class ShardedDatabase:
         lo, hi = shard_range(n, rank, world)
         s_off, s_ids, s_data = slice_csr(off, ids, data, lo, hi)
         return cls(engine.pack_host(s_off, s_ids, s_data, width), lo, hi, n, width, engine, group)
+
+    @classmethod
+    def from_file(cls, path, *, engine, rank: int, world: int, group=None):
+        """Every rank maps the same CSR database file and packs only its row range, straight from
+        the mapping (no rank ever holds the whole database in host memory)."""
+        from . import csrfile
+        meta = csrfile.info(path)
+        lo, hi = shard_range(meta["n_rows"], rank, world)
+        return cls(engine.pack_file(path, lo, hi), lo, hi, meta["n_rows"], meta["width"], engine, group)
 
     # -- the exchange step ------------------------------------------------------------
     def broadcast_queries(self, packed=None, src: int = 0, force_collective: bool = False, into=None):

@@ -3,10 +3,12 @@
 // is compared with the reference's per-pair call using the reference's operator== (ids and
 // payloads, SDR.hpp:470-483).  Built only where /root/reference exists (oracle/Makefile ->
 // oracle/_ref/test_sdrbatch); the GPU test-suite runs the binary when it is present.
+#include <algorithm>
 #include <cstdio>
 #include <forward_list>
 #include <random>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "SparseDistributedRepresentation/SDR.hpp"
@@ -70,6 +72,53 @@ int run(const char* name, std::mt19937& rng, int width, int32_t declared_width) 
     return 0;
 }
 
+// all-pairs top-k of a database with itself: every count is the reference's ands, the order is
+// overlap descending then row ascending, the self match is excluded
+int run_allpairs(std::mt19937& rng, unsigned flags, const char* name) {
+    using E = SDRElem<>;
+    auto ds = make_rows<SDR<E>>(rng, 333, 512, 40);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 512);
+    const uint32_t k = 7;
+    auto top = d.allpairs_topk(d, k, 0, flags);
+    auto counts = top.counts_to_host();
+    auto rows = top.rows_to_host();
+    for (size_t i = 0; i < ds.size(); ++i) {
+        std::vector<std::pair<long, long>> cand;   // (-overlap, row)
+        for (size_t j = 0; j < ds.size(); ++j)
+            if (j != i) cand.push_back({-(long)ds[i].ands(ds[j]), (long)j});
+        std::sort(cand.begin(), cand.end());
+        for (uint32_t t = 0; t < k; ++t) {
+            REQUIRE(rows[i * k + t] == cand[t].second);
+            REQUIRE((long)counts[i * k + t] == -cand[t].first);
+        }
+    }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
+// database files: SDR objects -> file -> SDR objects (reference operator==), and a batch loaded from
+// a row range of the file gives the reference's counts
+template <typename SDR_t>
+int run_file(std::mt19937& rng, const char* name) {
+    auto ds = make_rows<SDR_t>(rng, 500, 400, 40);
+    const std::string path = std::string("/tmp/sdrb_cpp_test_") + name + ".sdrb";
+    sdr_amd::save(ds.begin(), ds.end(), path, 400, 64);   // 8 chunks
+    using R = SDR<typename SDR_t::value_type, std::vector<typename SDR_t::value_type>>;
+    auto back = sdr_amd::load_rows<R>(path);
+    REQUIRE(back.size() == ds.size());
+    for (size_t r = 0; r < ds.size(); ++r) REQUIRE(back[r] == ds[r]);
+    auto part = sdr_amd::load_rows<R>(path, 100, 130);
+    for (size_t r = 0; r < part.size(); ++r) REQUIRE(part[r] == ds[100 + r]);
+    auto shard = sdr_amd::SDRBatch::from_file(path, 0, 100, 400);
+    auto q = sdr_amd::SDRBatch::pack(ds.begin(), ds.begin() + 20, 0, 400);
+    auto counts = q.ands(shard).to_host();
+    for (size_t i = 0; i < 20; ++i)
+        for (size_t j = 0; j < 300; ++j) REQUIRE(counts[i * 300 + j] == ds[i].ands(ds[100 + j]));
+    std::remove(path.c_str());
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
 int main() {
     std::mt19937 rng(12345);
     using E = SDRElem<>;
@@ -82,6 +131,10 @@ int main() {
         if (run<SDR<U>, SDR<E>>("unit x empty", rng, 200, 200)) return 1;
         if (run<SDR<E>, SDR<U>>("empty x unit", rng, 200, 200)) return 1;
         if (run<SDR<U, IDContiguousContainer<U>>, SDR<U, IDContiguousContainer<U>>>("idcontiguous x idcontiguous", rng, 200, 0)) return 1;
+        if (run_file<SDR<E>>(rng, "file_empty")) return 1;
+        if (run_file<SDR<U>>(rng, "file_unit")) return 1;
+        if (run_allpairs(rng, 0, "all-pairs top-k (default)")) return 1;
+        if (run_allpairs(rng, SDRB_FLAG_FORCE_MFMA, "all-pairs top-k (matrix cores)")) return 1;
     } catch (const sdr_amd::Error& e) {
         std::printf("FAIL sdr_amd::Error %d: %s\n", e.code(), e.what());
         return 1;

@@ -313,3 +313,30 @@ def test_adopted_view_equals_uploaded_batch(with_data):
         a, b = view.xore(db).to_host(), up.xore(db).to_host()
         for x, y in zip(a, b):
             assert (x is None and y is None) or np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_data", [False, True])
+def test_batch_from_database_file_equals_batch_from_arrays(tmp_path, with_data):
+    """A row range uploaded straight from a CSR database file behaves like the same rows uploaded
+    from arrays; payloads of a UnitData file can be dropped at load time."""
+    import torch
+    from sdr_amd import csrfile
+    rng = np.random.default_rng(31)
+    off, ids, data = util.ragged_rows(rng, 800, 2048, 40, with_data)
+    path = tmp_path / "db.sdrb"
+    csrfile.write(path, off, ids, data, width=2048)
+    q = SDRBatch.from_csr(*util.ragged_rows(rng, 33, 2048, 40, with_data), width=2048)
+    lo, hi = 123, 700
+    s_off = off[lo:hi + 1] - off[lo]
+    s_ids = ids[int(off[lo]):int(off[hi])]
+    s_data = None if data is None else data[int(off[lo]):int(off[hi])]
+    a = csrfile.upload_rows(path, lo, hi)
+    b = SDRBatch.from_csr(s_off, s_ids, s_data, width=2048)
+    assert a.stats() == b.stats()
+    for name in ("ands", "ors", "xors", "rms"):
+        assert torch.equal(getattr(q, name)(a), getattr(q, name)(b)), name
+    if with_data:
+        ids_only = csrfile.upload_rows(path, lo, hi, payloads=False)
+        want = SDRBatch.from_csr(s_off, s_ids, None, width=2048)
+        assert torch.equal(q.ands(ids_only), q.ands(want))

@@ -33,6 +33,11 @@ class OracleEngine:
         import oracle
         return oracle.Batch(off, ids, data)
 
+    def pack_file(self, path, row_lo, row_hi):
+        import oracle
+        from sdr_amd import csrfile
+        return oracle.Batch(*csrfile.read_rows(path, row_lo, row_hi))
+
     def pack_device(self, off_t, ids_t, data_t, width):
         import oracle
         return oracle.Batch(off_t.numpy().astype(np.uint64), ids_t.numpy(),
@@ -75,7 +80,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, with_data, n_rows, results):
+def _worker(rank, world, port, with_data, n_rows, results, tmpdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -85,6 +90,17 @@ def _worker(rank, world, port, with_data, n_rows, results):
         db = ShardedDatabase.from_global_csr(d_off, d_ids, d_data, width=300, engine=OracleEngine(),
                                              rank=rank, world=world)
         assert (db.row_lo, db.row_hi) == shard_range(n_rows, rank, world)
+        # the same shard, packed from a database file that rank 0 wrote
+        from sdr_amd import csrfile
+        path = os.path.join(tmpdir, "db.sdrb")
+        if rank == 0:
+            csrfile.write(path, d_off, d_ids, d_data, width=300)
+        dist.barrier()
+        from_file = ShardedDatabase.from_file(path, engine=OracleEngine(), rank=rank, world=world)
+        assert (from_file.row_lo, from_file.row_hi, from_file.n_rows_total, from_file.width) == \
+            (db.row_lo, db.row_hi, n_rows, 300)
+        for got, want in zip(from_file.shard.csr(), db.shard.csr()):
+            assert (got is None and want is None) or np.array_equal(got, want)
         packed = None
         if rank == 0:
             packed = (torch.from_numpy(q_off.astype(np.int64).astype(np.int32)), torch.from_numpy(q_ids),
@@ -119,12 +135,12 @@ def _worker(rank, world, port, with_data, n_rows, results):
 
 
 @pytest.mark.parametrize("with_data,n_rows", [(False, 101), (True, 64)])
-def test_two_rank_sharded_size_ops(with_data, n_rows):
+def test_two_rank_sharded_size_ops(with_data, n_rows, tmp_path):
     import oracle
     world = 2
     mgr = mp.Manager()
     results = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), with_data, n_rows, results), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), with_data, n_rows, results, str(tmp_path)), nprocs=world, join=True)
     rng = np.random.default_rng(5)
     d = oracle.Batch(*util.ragged_rows(rng, n_rows, 300, 40, with_data))
     q = oracle.Batch(*util.ragged_rows(rng, 9, 300, 40, with_data))
