@@ -52,6 +52,9 @@ extern "C" {
 /* payload kinds of a batch's elements */
 #define SDRB_DATA_EMPTY 0 /* DataTypes/EmptyData.hpp:18-92: zero-size payload */
 #define SDRB_DATA_UNIT 1  /* DataTypes/UnitData.hpp:11-140: float in [0,1] */
+#define SDRB_DATA_ARITH 2 /* DataTypes/ArithData.hpp:11-107 with arith_t = float; payloads must be finite here
+                             (the reference allows any float); only sdrb_inner and the payload-blind
+                             sdrb_allpairs_topk take such batches */
 
 /* flags of the binary operations */
 #define SDRB_FLAG_SWAP 1u           /* result(i,j) = B_j.op(A_i) instead of A_i.op(B_j) */
@@ -148,6 +151,20 @@ int sdrb_batch_destroy(sdrb_batch* batch);
  */
 int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                  uint32_t* out, uint64_t ld_out, void* stream);
+
+/*
+ * Sparse dot products for every pair: out[i*ld_out + j] (float, device memory, ld_out >= B rows)
+ *   = A_i.inner(B_j)  (SDR.hpp:1682-1692): over the id matches in ascending id order,
+ *     acc += a_value * b_value, a rounded product followed by a rounded sum (ArithData.hpp:37-43,
+ *     59-63), starting from 0; bit-exact against the reference.
+ * `a` must be an SDRB_DATA_ARITH batch; `b` is SDRB_DATA_ARITH, or SDRB_DATA_EMPTY (its matches add
+ * a_value unchanged, ArithData.hpp:39).  The same numbers are entry (i, j) of diff_mul when `a`
+ * holds the rows of a row-major matrix and `b` the columns of a column-major one (SDR.hpp:1886-1923),
+ * and entry j of row_major_mul_vec(vector) when `a` holds the single vector and `b` the matrix rows
+ * (SDR.hpp:1729-1750; ArithData is always relevant, so no entry is dropped).
+ */
+int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
+               void* stream);
 
 /*
  * All-pairs overlap with a fused per-row top-k.  For every row i of `a`, the k rows j of `b`

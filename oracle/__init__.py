@@ -93,6 +93,19 @@ class _Impl:
         getattr(self.lib, self.prefix + "batch_size_op")(op, *t.args(), *a.args(), out.ctypes.data_as(_vp))
         return out
 
+    def inner(self, t: Batch, a: Batch) -> np.ndarray:
+        """float32 [t.n, a.n]: this_i.inner(arg_j) with ArithData<float> payloads on ``t`` and
+        ArithData<float> (``a.data`` given) or EmptyData (``a.data`` None) on ``a``."""
+        fn = getattr(self.lib, self.prefix + "batch_inner")
+        fn.restype, fn.argtypes = None, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp]
+        if t.data is None:
+            raise ValueError("inner needs payloads on the this side")
+        out = np.zeros((t.n, a.n), dtype=np.float32)
+        fn(t.off.ctypes.data_as(_vp), t.ids.ctypes.data_as(_vp), t.data.ctypes.data_as(_vp), t.n,
+           a.off.ctypes.data_as(_vp), a.ids.ctypes.data_as(_vp),
+           a.data.ctypes.data_as(_vp) if a.data is not None else None, a.n, out.ctypes.data_as(_vp))
+        return out
+
     def elem_op(self, op: int, t: Batch, a: Batch, inplace: bool = False):
         """Returns (offsets uint64[t.n*a.n+1], ids, data-or-None) of this_i.op(arg_j)."""
         fn = getattr(self.lib, self.prefix + "batch_elem_op")

@@ -13,6 +13,7 @@
  * no relevance filtering, ascending order asserted).
  */
 #include "SparseDistributedRepresentation/SDR.hpp"
+#include "SparseDistributedRepresentation/DataTypes/ArithData.hpp"
 #include "SparseDistributedRepresentation/DataTypes/UnitData.hpp"
 
 #include <chrono>
@@ -194,6 +195,30 @@ uint64_t rsdr_batch_elem_op(int op, int inplace,
 }
 
 /* a.op(a) with the SAME object on both sides (src/test.cpp:241-272). Returns new length. */
+/* this_i.inner(arg_j) on SDR<SDRElem<int, ArithData<float>>> rows (SDR.hpp:1682-1692); a_data == NULL:
+ * the argument rows are SDR<SDRElem<int, EmptyData>>.  Also checks that diff_mul on the same rows,
+ * taken as a row-major and a column-major matrix, produces the same entries (SDR.hpp:1886-1923). */
+void rsdr_batch_inner(const uint64_t* t_off, const int32_t* t_ids, const float* t_data, uint64_t t_n,
+                      const uint64_t* a_off, const int32_t* a_ids, const float* a_data, uint64_t a_n,
+                      float* out) {
+    using ArithElem = SDRElem<int, ArithData<float>>;
+    using ArithSDR = SDR<ArithElem>;
+    std::vector<ArithSDR> t(t_n);
+    for (uint64_t r = 0; r < t_n; ++r)
+        for (uint64_t k = t_off[r]; k < t_off[r + 1]; ++k) t[r].push_back(ArithElem(t_ids[k], ArithData<float>(t_data[k])));
+    if (a_data) {
+        std::vector<ArithSDR> a(a_n);
+        for (uint64_t r = 0; r < a_n; ++r)
+            for (uint64_t k = a_off[r]; k < a_off[r + 1]; ++k) a[r].push_back(ArithElem(a_ids[k], ArithData<float>(a_data[k])));
+        for (uint64_t i = 0; i < t_n; ++i)
+            for (uint64_t j = 0; j < a_n; ++j) out[i * a_n + j] = t[i].inner<ArithData<float>>(a[j]).value();
+    } else {
+        std::vector<EmptySDR> a = build<EmptySDR>(a_off, a_ids, nullptr, a_n);
+        for (uint64_t i = 0; i < t_n; ++i)
+            for (uint64_t j = 0; j < a_n; ++j) out[i * a_n + j] = t[i].inner<ArithData<float>>(a[j]).value();
+    }
+}
+
 uint64_t rsdr_inplace_self(int op, int32_t* ids, float* data, uint64_t n, int kind) {
     uint64_t off[2] = {0, n};
     uint64_t len = 0;

@@ -359,6 +359,39 @@ static osdr_view row_view(const uint64_t* off, const int32_t* ids, const float* 
     return v;
 }
 
+/* ---- inner (SDR.hpp:1682-1692) ---------------------------------------------------------- */
+typedef struct {
+    const float* t_data;
+    const float* a_data;
+    float acc;
+} inner_ctx;
+
+static void inner_visit(void* vctx, size_t this_pos, size_t arg_pos) {
+    inner_ctx* c = (inner_ctx*)vctx;
+    /* elem = this_pos->data().ande(arg_pos->data()): value_ *= o.value() unless o is EmptyData
+     * (ArithData.hpp:30-43); one rounding */
+    volatile float elem = c->t_data[this_pos];
+    if (c->a_data) elem = elem * c->a_data[arg_pos];
+    /* ret.ori(elem): value_ += o.value() (ArithData.hpp:53-63); a second rounding, never fused */
+    volatile float sum = c->acc + elem;
+    c->acc = sum;
+}
+
+void osdr_batch_inner(const uint64_t* t_off, const int32_t* t_ids, const float* t_data, uint64_t t_n,
+                      const uint64_t* a_off, const int32_t* a_ids, const float* a_data, uint64_t a_n,
+                      float* out) {
+    for (uint64_t i = 0; i < t_n; ++i)
+        for (uint64_t j = 0; j < a_n; ++j) {
+            inner_ctx c;
+            c.t_data = t_data + t_off[i];
+            c.a_data = a_data ? a_data + a_off[j] : NULL;
+            c.acc = 0.0f;   /* ArithData() (ArithData.hpp:16) */
+            osdr_andv(t_ids + t_off[i], (size_t)(t_off[i + 1] - t_off[i]), a_ids + a_off[j],
+                      (size_t)(a_off[j + 1] - a_off[j]), inner_visit, &c);
+            out[i * a_n + j] = c.acc;
+        }
+}
+
 void osdr_batch_size_op(int op,
                         const uint64_t* t_off, const int32_t* t_ids, const float* t_data,
                         int t_kind, uint64_t t_n,

@@ -69,6 +69,17 @@ size_t osdr_inplace_op(int op, int32_t* t_ids, float* t_data, size_t t_n, int t_
                        const osdr_view* a);
 
 /* Host loops over CSR batches: out[i*a_n + j] = this_i.op(arg_j). */
+/* SDR::inner on ArithData<float> elements (SDR.hpp:1682-1692): for every id match, in ascending
+ * id order, acc += this_value * arg_value -- a rounded product (ArithData.hpp:37-43, value_ *=)
+ * followed by a rounded sum (ArithData.hpp:59-63, value_ +=), starting from ArithData() = 0
+ * (ArithData.hpp:16).  An EmptyData argument leaves the value unchanged (ArithData.hpp:39), so
+ * its matches add this_value.  a_data == NULL means the argument rows carry no payload.
+ * out[i * a_n + j] = this_i.inner(arg_j); also diff_mul's entry (i, j) (SDR.hpp:1886-1923) and
+ * row_major_mul_vec's entry for row j when this is the vector (SDR.hpp:1729-1750). */
+void osdr_batch_inner(const uint64_t* t_off, const int32_t* t_ids, const float* t_data, uint64_t t_n,
+                      const uint64_t* a_off, const int32_t* a_ids, const float* a_data, uint64_t a_n,
+                      float* out);
+
 void osdr_batch_size_op(int op,
                         const uint64_t* t_off, const int32_t* t_ids, const float* t_data,
                         int t_kind, uint64_t t_n,

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SDR_AMD_LIB") or os.path.join(_HERE, "libsdr_amd.so")
 
 OK = 0
 OP_AND, OP_OR, OP_XOR, OP_RM = 0, 1, 2, 3
-DATA_EMPTY, DATA_UNIT = 0, 1
+DATA_EMPTY, DATA_UNIT, DATA_ARITH = 0, 1, 2
 FLAG_SWAP, FLAG_FORCE_MERGE, FLAG_FORCE_BITSLICE, FLAG_FORCE_POPCOUNT, FLAG_FORCE_MFMA = 1, 2, 4, 8, 16
 
 ERROR_NAMES = {
@@ -63,6 +63,7 @@ PROTOTYPES = {
     "sdrb_file_read_rows": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     "sdrb_batch_upload_file": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_uint64, _vp]),
     "sdrb_size_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
+    "sdrb_inner": (C.c_int, [_vp, _vp, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_allpairs_topk": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int64, C.c_uint, _vp, _vp, _vp]),
     "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
     "sdrb_elem_op_fill": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),

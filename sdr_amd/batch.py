@@ -16,10 +16,11 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_SWAP,
+from ._lib import (DATA_ARITH, DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_SWAP,
                    OP_AND, OP_OR, OP_RM, OP_XOR, check)
 
-_KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT}
+_KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, "arith": DATA_ARITH, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT,
+          DATA_ARITH: DATA_ARITH}
 
 
 def _torch():
@@ -88,8 +89,10 @@ class SDRBatch:
 
     # -- construction -------------------------------------------------------------
     @classmethod
-    def from_csr(cls, offsets, ids, data=None, *, width: int = 0, device: int = 0, stream=None):
-        b = cls(device, width, "unit" if data is not None else "empty")
+    def from_csr(cls, offsets, ids, data=None, *, width: int = 0, device: int = 0, stream=None, kind=None):
+        """``kind``: "empty" / "unit" / "arith"; by default "unit" when payloads are given (UnitData,
+        values in [0,1]); "arith" takes any finite float (ArithData<float>, for :meth:`inner`)."""
+        b = cls(device, width, kind if kind is not None else ("unit" if data is not None else "empty"))
         b.upload(offsets, ids, data, stream=stream)
         return b
 
@@ -106,9 +109,9 @@ class SDRBatch:
         if int(off[-1]) != ids.size:
             raise ValueError("offsets[-1] must equal len(ids)")
         dptr = None
-        if self.data_kind == DATA_UNIT:
+        if self.data_kind != DATA_EMPTY:
             if data is None:
-                raise ValueError("UnitData batch needs payloads")
+                raise ValueError("a batch with payloads needs them")
             data = np.ascontiguousarray(data, dtype=np.float32)
             if data.size != ids.size:
                 raise ValueError("data and ids differ in length")
@@ -140,7 +143,7 @@ class SDRBatch:
         if not (offsets.is_contiguous() and ids.is_contiguous()):
             raise ValueError("offsets and ids must be contiguous")
         dptr = None
-        if self.data_kind == DATA_UNIT:
+        if self.data_kind != DATA_EMPTY:
             if data is None or data.dtype != torch.float32 or not data.is_contiguous() or data.numel() != ids.numel():
                 raise ValueError("UnitData batch needs a contiguous float32 payload tensor as long as ids")
             dptr = data.data_ptr() if data.numel() else None
@@ -165,7 +168,7 @@ class SDRBatch:
         if offsets.dtype != torch.int32 or ids.dtype != torch.int32 or not offsets.is_contiguous() \
                 or not ids.is_contiguous():
             raise ValueError("offsets and ids must be contiguous int32 tensors")
-        if (self.data_kind == DATA_UNIT) != (data is not None):
+        if (self.data_kind != DATA_EMPTY) != (data is not None):
             raise ValueError("payload tensor must be given exactly for UnitData batches")
         n_rows, nnz = offsets.numel() - 1, ids.numel()
         check(self._lib.sdrb_batch_adopt_device_csr(
@@ -179,7 +182,7 @@ class SDRBatch:
         payload bits (nnz, UnitData only)]`` (a device-to-device copy), the sending side of
         :meth:`adopt_device`."""
         torch = _torch()
-        unit = self.data_kind == DATA_UNIT
+        unit = self.data_kind != DATA_EMPTY
         words = self.n_rows + 1 + self.nnz * (2 if unit else 1)
         wire = torch.empty(words, dtype=torch.int32, device=f"cuda:{self.device}")
         ids_t = wire[self.n_rows + 1: self.n_rows + 1 + self.nnz]
@@ -194,7 +197,7 @@ class SDRBatch:
         lo, hi = C.c_int32(), C.c_int32()
         check(self._lib.sdrb_batch_id_span(self._h, C.byref(lo), C.byref(hi)))
         return dict(n_rows=self.n_rows, nnz=self.nnz, max_row_len=self.max_row_len,
-                    min_id=int(lo.value), max_id=int(hi.value), has_data=self.data_kind == DATA_UNIT)
+                    min_id=int(lo.value), max_id=int(hi.value), has_data=self.data_kind != DATA_EMPTY)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
@@ -234,6 +237,23 @@ class SDRBatch:
         check(self._lib.sdrb_size_op(self._h, other._h, op, self._flags(swap, algo),
                                      out.data_ptr(), out.stride(0),
                                      _stream_handle(other.device, stream)))
+        return out
+
+    def inner(self, other: "SDRBatch", *, out=None, stream=None):
+        """``out[i, j] = self[i].inner(other[j])`` (float32): the sparse dot product over the id
+        matches in ascending id order, product and sum rounded separately, bit-exact against the
+        reference (``SDR.hpp:1682-1692``).  ``self`` must be an "arith" batch, ``other`` "arith" or
+        "empty".  With ``self`` = the rows of a row-major matrix and ``other`` = the columns of a
+        column-major one this is ``diff_mul``; with ``self`` = one vector and ``other`` = matrix
+        rows, ``row_major_mul_vec``."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty((self.n_rows, other.n_rows), dtype=torch.float32, device=f"cuda:{other.device}")
+        if out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] < self.n_rows \
+                or out.shape[1] < other.n_rows or out.stride(1) != 1:
+            raise ValueError("out must be a float32 [>=na, >=nb] tensor with unit inner stride")
+        check(self._lib.sdrb_inner(self._h, other._h, 0, out.data_ptr(), out.stride(0),
+                                   _stream_handle(other.device, stream)))
         return out
 
     def allpairs_topk(self, other: "SDRBatch", k: int, *, exclude_offset: int = -1, stream=None, algo=None):

@@ -68,7 +68,7 @@ void free_batch_storage(sdrb_batch* b) {
 // enough (repeated uploads of similar batches, e.g. one query batch per step, then cost no
 // hipMalloc/hipFree).  Derived data of the previous content is dropped.
 int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
-    const bool unit = b->data_kind == SDRB_DATA_UNIT;
+    const bool unit = has_payload(b);
     drop_derived(b);
     if (b->owns_storage && b->d_offsets && b->cap_rows >= n_rows && b->cap_nnz >= nnz) return SDRB_OK;
     free_batch_storage(b);
@@ -87,14 +87,14 @@ struct PackStats {
     int32_t max_id;
     uint32_t bad_offsets;   // 1 + first row whose offsets are not monotone / exceed nnz
     uint32_t bad_order;     // 1 + a row that is not strictly ascending
-    uint32_t bad_payload;   // 1 + an element whose UnitData payload is outside [0,1]
+    uint32_t bad_payload;   // 1 + an element whose payload is outside [0,1] (UnitData) or not finite (ArithData)
     uint32_t nnz;           // row_offsets[n_rows]
 };
 
 __global__ __launch_bounds__(256) void k_validate_pack(const uint32_t* __restrict__ off,
                                                        const int32_t* __restrict__ ids,
-                                                       const float* __restrict__ data, uint64_t n_rows,
-                                                       PackStats* __restrict__ st) {
+                                                       const float* __restrict__ data, int data_kind,
+                                                       uint64_t n_rows, PackStats* __restrict__ st) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t nnz = off[n_rows];
     if (r == 0) st->nnz = nnz;
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void k_validate_pack(const uint32_t* __restric
     bool order_ok = true, payload_ok = true;
     for (uint32_t k = lo; k < hi; ++k) {
         if (k > lo && ids[k] <= ids[k - 1]) order_ok = false;
-        if (data && !(data[k] >= 0.0f && data[k] <= 1.0f)) payload_ok = false;
+        if (data_kind == SDRB_DATA_UNIT && !(data[k] >= 0.0f && data[k] <= 1.0f)) payload_ok = false;
+        if (data_kind == SDRB_DATA_ARITH && !(fabsf(data[k]) <= 3.402823466e38f)) payload_ok = false;
     }
     if (!order_ok) atomicMin(&st->bad_order, (uint32_t)(r + 1));
     if (!payload_ok) atomicMin(&st->bad_payload, (uint32_t)(r + 1));
@@ -142,6 +143,15 @@ int check_pair(const sdrb_batch* a, const sdrb_batch* b, int op) {
     if (!a->d_offsets || !b->d_offsets) {
         set_error("batch has no uploaded rows");
         return SDRB_ERR_INVALID_ARG;
+    }
+    return SDRB_OK;
+}
+
+// the set algebra is implemented for EmptyData and UnitData payloads
+int check_set_algebra_kinds(const sdrb_batch* a, const sdrb_batch* b) {
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) {
+        set_error("ArithData batches are taken by sdrb_inner only");
+        return SDRB_ERR_UNSUPPORTED;
     }
     return SDRB_OK;
 }
@@ -203,7 +213,7 @@ int sdrb_device_count(int* count) {
 
 int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out) {
     if (!out || width < 0 || device < 0 ||
-        (data_kind != SDRB_DATA_EMPTY && data_kind != SDRB_DATA_UNIT)) {
+        (data_kind != SDRB_DATA_EMPTY && data_kind != SDRB_DATA_UNIT && data_kind != SDRB_DATA_ARITH)) {
         set_error("sdrb_batch_create: bad argument (device=%d width=%d data_kind=%d)", device, width,
                   data_kind);
         return SDRB_ERR_INVALID_ARG;
@@ -240,9 +250,9 @@ int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* ro
         set_error("ids is null");
         return SDRB_ERR_INVALID_ARG;
     }
-    const bool unit = batch->data_kind == SDRB_DATA_UNIT;
+    const bool unit = has_payload(batch);
     if (unit && nnz > 0 && !data) {
-        set_error("UnitData batch needs a payload array");
+        set_error("a batch with payloads needs a payload array");
         return SDRB_ERR_INVALID_ARG;
     }
 
@@ -280,7 +290,16 @@ int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* ro
                   batch->width);
         return SDRB_ERR_ID_RANGE;
     }
-    if (unit) {
+    if (batch->data_kind == SDRB_DATA_ARITH) {
+        // the dot-product kernels rely on finite payloads (a term of an absent id must be a zero)
+        for (uint64_t k = 0; k < nnz; ++k) {
+            if (!std::isfinite(data[k])) {
+                set_error("ArithData payload at element %llu is not finite", (unsigned long long)k);
+                return SDRB_ERR_PAYLOAD_RANGE;
+            }
+        }
+    }
+    if (batch->data_kind == SDRB_DATA_UNIT) {
         for (uint64_t k = 0; k < nnz; ++k) {
             if (!(data[k] >= 0.0f && data[k] <= 1.0f)) {
                 set_error("UnitData payload %g at element %llu is outside [0,1]", (double)data[k],
@@ -324,7 +343,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
         set_error("too many rows for 32-bit offsets");
         return SDRB_ERR_OVERFLOW;
     }
-    const bool unit = batch->data_kind == SDRB_DATA_UNIT;
+    const bool unit = has_payload(batch);
     DeviceGuard guard(batch->device);
     if (!guard.ok) {
         set_error("hipSetDevice(%d) failed", batch->device);
@@ -346,7 +365,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
     SDRB_HIP(hipMemcpyAsync(d_st, &init, sizeof init, hipMemcpyHostToDevice, s));
     // one pass over the rows: total element count, row checks, id span (grid covers >= 1 thread)
     hipLaunchKernelGGL(k_validate_pack, dim3((uint32_t)((n_rows + 256) / 256)), dim3(256), 0, s, row_offsets,
-                       ids, unit ? data : nullptr, n_rows, d_st);
+                       ids, data, batch->data_kind, n_rows, d_st);
     SDRB_HIP(hipGetLastError());
     PackStats st;
     SDRB_HIP(hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, s));
@@ -361,7 +380,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
         return SDRB_ERR_NOT_ASCENDING;
     }
     if (st.bad_payload != 0xFFFFFFFFu) {
-        set_error("row %u holds a UnitData payload outside [0,1]", st.bad_payload - 1);
+        set_error("row %u holds a payload outside [0,1] (UnitData) or a NaN / infinity (ArithData)", st.bad_payload - 1);
         return SDRB_ERR_PAYLOAD_RANGE;
     }
     const bool any = st.max_len > 0;
@@ -391,7 +410,7 @@ int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz
                                 const int32_t* ids, const float* data, uint32_t max_row_len,
                                 int32_t min_id, int32_t max_id) {
     if (!batch || !row_offsets || (nnz && !ids) ||
-        (nnz && batch->data_kind == SDRB_DATA_UNIT && !data)) {
+        (nnz && has_payload(batch) && !data)) {
         set_error("sdrb_batch_adopt_device_csr: null argument");
         return SDRB_ERR_INVALID_ARG;
     }
@@ -408,7 +427,7 @@ int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz
     batch->owns_storage = false;
     batch->d_offsets = const_cast<uint32_t*>(row_offsets);
     batch->d_ids = const_cast<int32_t*>(ids);
-    batch->d_data = batch->data_kind == SDRB_DATA_UNIT ? const_cast<float*>(data) : nullptr;
+    batch->d_data = has_payload(batch) ? const_cast<float*>(data) : nullptr;
     batch->n_rows = n_rows;
     batch->nnz = nnz;
     batch->max_row_len = max_row_len;
@@ -445,7 +464,7 @@ int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id
 int sdrb_batch_export_device_csr(const sdrb_batch* batch, uint32_t* row_offsets, int32_t* ids, float* data,
                                  void* stream) {
     if (!batch || !batch->d_offsets || !row_offsets || (batch->nnz && !ids) ||
-        (batch->nnz && batch->data_kind == SDRB_DATA_UNIT && !data)) {
+        (batch->nnz && has_payload(batch) && !data)) {
         set_error("sdrb_batch_export_device_csr: null argument or empty handle");
         return SDRB_ERR_INVALID_ARG;
     }
@@ -455,7 +474,7 @@ int sdrb_batch_export_device_csr(const sdrb_batch* batch, uint32_t* row_offsets,
                             hipMemcpyDeviceToDevice, s));
     if (batch->nnz) {
         SDRB_HIP(hipMemcpyAsync(ids, batch->d_ids, batch->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        if (batch->data_kind == SDRB_DATA_UNIT)
+        if (has_payload(batch))
             SDRB_HIP(hipMemcpyAsync(data, batch->d_data, batch->nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return SDRB_OK;
@@ -486,6 +505,7 @@ int sdrb_batch_destroy(sdrb_batch* batch) {
 int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                  uint64_t ld_out, void* stream) {
     int rc = check_pair(a, b, op);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
     if (rc != SDRB_OK) return rc;
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
     if (!out || ld_out < b->n_rows) {
@@ -522,6 +542,29 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return launch_size_merge(a, b, op, swap, out, ld_out, s);
 }
 
+int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
+               void* stream) {
+    (void)flags;
+    int rc = check_pair(a, b, SDRB_OP_AND);
+    if (rc != SDRB_OK) return rc;
+    if (a->data_kind != SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_UNIT) {
+        set_error("sdrb_inner takes an ArithData batch and an ArithData or EmptyData batch");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || ld_out < b->n_rows) {
+        set_error("sdrb_inner: out is null or ld_out (%llu) < rows of b (%llu)", (unsigned long long)ld_out,
+                  (unsigned long long)b->n_rows);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_inner(a, b, out, ld_out, static_cast<hipStream_t>(stream));
+}
+
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
     int rc = check_pair(a, b, SDRB_OP_AND);
@@ -554,6 +597,7 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                        uint32_t* out_offsets, uint64_t* total, void* stream) {
     int rc = check_pair(a, b, op);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
     if (rc != SDRB_OK) return rc;
     if (!out_offsets || !total) {
         set_error("sdrb_elem_op_count: null output");
@@ -600,6 +644,7 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                       const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
     int rc = check_pair(a, b, op);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
     if (rc != SDRB_OK) return rc;
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
     const bool swap = (flags & SDRB_FLAG_SWAP) != 0;

@@ -29,11 +29,14 @@ struct sdrb_batch {
 
 namespace sdrb {
 
+// does the batch carry a float per element (UnitData or ArithData<float>)?
+inline bool has_payload(const sdrb_batch* b) { return b->data_kind != SDRB_DATA_EMPTY; }
+
 void set_error(const char* fmt, ...);
 
 // Per-device scratch that grows on demand and lives until process exit.
 // slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
-// slot 4: partial top-k lists.
+// slot 4: partial top-k lists; slot 5: interleaved value table of A (dot products).
 void* workspace(int device, int slot, size_t bytes);
 
 #define SDRB_HIP(call)                                                                   \
@@ -100,6 +103,10 @@ int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t 
 int launch_merge_topk(const int* partial, uint32_t na, uint32_t splits, uint32_t lists_per_split,
                       uint64_t rows_per_split, uint32_t k, uint32_t* out_counts, int32_t* out_rows,
                       hipStream_t stream);
+
+// inner.hip --------------------------------------------------------------------------------
+// Sparse dot products of ArithData<float> rows for every pair (SDR::inner, SDR.hpp:1682-1692).
+int launch_inner(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t ld_out, hipStream_t stream);
 
 // unit_table.hip --------------------------------------------------------------------
 // Wave-per-row kernels with an LDS position table of one row of A (declared width <= 32768).

@@ -104,6 +104,31 @@ def _one(op, t_rows, a_rows, t_data=False, a_data=False):
     return ids.tolist(), (None if data is None else data.tolist())
 
 
+@pytest.mark.parametrize("tag", ["small", "c2like", "long"])
+def test_inner_golden(golden, tag):
+    """Sparse dot products (inner / diff_mul / row_major_mul_vec on ArithData<float>,
+    SDR.hpp:1682-1692): the restatement reproduces the reference's float bits."""
+    g = golden("inner.npz")
+    t = oracle.Batch(g[f"{tag}_t_off"], g[f"{tag}_t_ids"], g[f"{tag}_t_data"])
+    a = oracle.Batch(g[f"{tag}_a_off"], g[f"{tag}_a_ids"], g[f"{tag}_a_data"])
+    assert np.array_equal(oracle.port().inner(t, a).view(np.uint32), g[f"{tag}_aa_bits"])
+    assert np.array_equal(oracle.port().inner(t, oracle.Batch(a.off, a.ids, None)).view(np.uint32), g[f"{tag}_ae_bits"])
+    # the order of the terms matters: a float64 dot product rounded once differs somewhere
+    if tag != "small":
+        return
+    dense_t = np.zeros((t.n, 64)); dense_a = np.zeros((a.n, 64))
+    for r in range(t.n):
+        ids, data = t.row(r)
+        dense_t[r, ids] = data
+    for r in range(a.n):
+        ids, data = a.row(r)
+        dense_a[r, ids] = data
+    approx = (dense_t @ dense_a.T).astype(np.float32)
+    exact = g["small_aa_bits"].view(np.float32)
+    assert np.allclose(approx, exact, rtol=1e-4, atol=1e-3)
+    assert not np.array_equal(approx.view(np.uint32), g["small_aa_bits"])
+
+
 def test_readme_known_answers():
     # README.md:65-70
     assert _one(AND, [1, 2], [2, 3])[0] == [2]

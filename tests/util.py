@@ -131,3 +131,12 @@ def ragged_rows(rng: np.random.Generator, n_rows: int, width: int, max_len: int,
         off.append(len(ids))
     return (np.asarray(off, dtype=np.uint64), np.asarray(ids, dtype=np.int32),
             np.asarray(data, dtype=np.float32) if with_data else None)
+
+
+def arith_rows(rng: np.random.Generator, n_rows: int, width: int, max_len: int):
+    """Ragged rows with ArithData<float>-style payloads: signed values over six decades, so that
+    a sum's bits depend on the order of its terms."""
+    off, ids, _ = ragged_rows(rng, n_rows, width, max_len, False)
+    mag = 10.0 ** rng.uniform(-3.0, 3.0, ids.size)
+    data = (rng.standard_normal(ids.size) * mag).astype(np.float32)
+    return off, ids, data

@@ -158,10 +158,34 @@ def gen_inplace():
     np.savez_compressed(os.path.join(OUT, "inplace.npz"), seed=FUZZ_SEED, **out)
 
 
+def gen_inner():
+    """inner / diff_mul / row_major_mul_vec on ArithData<float> rows (SDR.hpp:1682-1692,1729-1750,
+    1886-1923): float bits of every pair, reference == restatement."""
+    rng = np.random.default_rng(FUZZ_SEED + 7)
+    out = {}
+    for tag, (nt, na, width, max_len) in {"small": (48, 96, 64, 40), "c2like": (16, 512, 2048, 40),
+                                          "long": (6, 64, 16384, 328)}.items():
+        t = oracle.Batch(*util.arith_rows(rng, nt, width, max_len))
+        a = oracle.Batch(*util.arith_rows(rng, na, width, max_len))
+        a_ids_only = oracle.Batch(a.off, a.ids, None)
+        for kind, arg in (("aa", a), ("ae", a_ids_only)):
+            ref = oracle.reference(debug=True).inner(t, arg)
+            mine = oracle.port().inner(t, arg)
+            assert np.array_equal(ref.view(np.uint32), mine.view(np.uint32)), (tag, kind)
+            out[f"{tag}_{kind}_bits"] = ref.view(np.uint32)
+        for name, b in (("t", t), ("a", a)):
+            out[f"{tag}_{name}_off"], out[f"{tag}_{name}_ids"], out[f"{tag}_{name}_data"] = b.off, b.ids, b.data
+    np.savez_compressed(os.path.join(OUT, "inner.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not oracle.have_reference():
         sys.exit("oracle/_ref is not built: this script needs /root/reference (make -C oracle)")
+    if sys.argv[1:] == ["inner"]:       # only the fixture of the sparse dot products
+        gen_inner()
+        return
+    gen_inner()
     gen_fuzz_sizes()
     gen_fuzz_elems()
     gen_mini("mini_2048_40.npz", 8, 4096, 2048, 40, False)
