@@ -61,6 +61,10 @@ extern "C" {
 #define SDRB_FLAG_FORCE_MERGE 2u    /* always use the general per-pair merge kernels */
 #define SDRB_FLAG_FORCE_BITSLICE 4u /* size ops: fail with UNSUPPORTED unless the bit-sliced kernel applies */
 #define SDRB_FLAG_FORCE_POPCOUNT 8u /* size ops: fail with UNSUPPORTED unless the dense-bitset popcount kernel applies */
+#define SDRB_FLAG_ROWWISE 32u       /* size/element ops: result j = A_j.op(B_j) for batches of equal length instead of
+                                       every pair; outputs have one entry per row (out[j], offsets[n+1]).  This is the
+                                       batched form of the in-place ops andi/ori/xori/rmi (SDR.hpp:1027-1081,1239-1292,
+                                       1366-1513), whose results equal those of the element ops */
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;

@@ -16,7 +16,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (DATA_ARITH, DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_SWAP,
+from ._lib import (DATA_ARITH, DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_ROWWISE, FLAG_SWAP,
                    OP_AND, OP_OR, OP_RM, OP_XOR, check)
 
 _KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, "arith": DATA_ARITH, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT,
@@ -214,8 +214,8 @@ class SDRBatch:
         return self.n_rows
 
     # -- size ops (SDR.hpp:175-176, 229-230, 257-258, 317-318) -------------------------
-    def _flags(self, swap: bool, algo: Optional[str]) -> int:
-        f = FLAG_SWAP if swap else 0
+    def _flags(self, swap: bool, algo: Optional[str], rowwise: bool = False) -> int:
+        f = (FLAG_SWAP if swap else 0) | (FLAG_ROWWISE if rowwise else 0)
         if algo == "merge":
             f |= FLAG_FORCE_MERGE
         elif algo == "bitslice":
@@ -286,14 +286,16 @@ class SDRBatch:
         return self._size_op(OP_RM, other, swap, out, stream, algo)
 
     # -- element ops (SDR.hpp:151-152, 209-212, 237-240, 292-293) ---------------------
-    def _elem_op(self, op: int, other: "SDRBatch", swap: bool, stream, algo) -> ElemResult:
+    def _elem_op(self, op: int, other: "SDRBatch", swap: bool, stream, algo, rowwise: bool = False) -> ElemResult:
         torch = _torch()
         dev = f"cuda:{other.device}"
-        pairs = self.n_rows * other.n_rows
+        if rowwise and self.n_rows != other.n_rows:
+            raise ValueError("row-wise evaluation needs batches of equal length")
+        pairs = other.n_rows if rowwise else self.n_rows * other.n_rows
         s = _stream_handle(other.device, stream)
         offsets = torch.empty(pairs + 1, dtype=torch.int32, device=dev)
         total = C.c_uint64()
-        flags = self._flags(swap, algo)
+        flags = self._flags(swap, algo, rowwise)
         check(self._lib.sdrb_elem_op_count(self._h, other._h, op, flags, offsets.data_ptr(),
                                            C.byref(total), s))
         n = int(total.value)
@@ -306,7 +308,44 @@ class SDRBatch:
                                           data_buf.data_ptr() if data_buf is not None else None, s))
         ids = ids_buf[:n]
         data = data_buf[:n] if data_buf is not None else None
-        return ElemResult(self.n_rows, other.n_rows, offsets, ids, data, n)
+        return ElemResult(1 if rowwise else self.n_rows, other.n_rows, offsets, ids, data, n)
+
+    # -- row-wise evaluation and the in-place ops ------------------------------------------------
+    def rowwise_size(self, name: str, other: "SDRBatch", *, swap=False, stream=None):
+        """``out[j] = self[j].<name>(other[j])`` for ``name`` in ands/ors/xors/rms and two batches
+        of equal length (int32 tensor [n])."""
+        torch = _torch()
+        op = {"ands": OP_AND, "ors": OP_OR, "xors": OP_XOR, "rms": OP_RM}[name]
+        out = torch.empty(max(other.n_rows, 1), dtype=torch.int32, device=f"cuda:{other.device}")
+        check(self._lib.sdrb_size_op(self._h, other._h, op, self._flags(swap, None, True), out.data_ptr(),
+                                     other.n_rows, _stream_handle(other.device, stream)))
+        return out[: other.n_rows]
+
+    def rowwise_elem(self, name: str, other: "SDRBatch", *, swap=False, stream=None) -> ElemResult:
+        """CSR of ``self[j].<name>(other[j])`` for ``name`` in ande/ore/xore/rme (one result per row)."""
+        op = {"ande": OP_AND, "ore": OP_OR, "xore": OP_XOR, "rme": OP_RM}[name]
+        return self._elem_op(op, other, swap, stream, None, rowwise=True)
+
+    def _inplace(self, name: str, other: "SDRBatch", stream) -> "SDRBatch":
+        res = self.rowwise_elem(name, other, stream=stream)
+        self.upload_device(res.offsets, res.ids, res.data, stream=stream)
+        return self
+
+    def andi(self, other, *, stream=None) -> "SDRBatch":
+        """Every row becomes ``row.andi(other[j])`` (SDR.hpp:1027-1081); the results equal ande's."""
+        return self._inplace("ande", other, stream)
+
+    def ori(self, other, *, stream=None) -> "SDRBatch":
+        """Every row becomes ``row.ori(other[j])`` (SDR.hpp:1239-1292)."""
+        return self._inplace("ore", other, stream)
+
+    def xori(self, other, *, stream=None) -> "SDRBatch":
+        """Every row becomes ``row.xori(other[j])`` (SDR.hpp:1366-1422)."""
+        return self._inplace("xore", other, stream)
+
+    def rmi(self, other, *, stream=None) -> "SDRBatch":
+        """Every row becomes ``row.rmi(other[j])`` (SDR.hpp:1436-1513)."""
+        return self._inplace("rme", other, stream)
 
     def ande(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
         return self._elem_op(OP_AND, other, swap, stream, algo)

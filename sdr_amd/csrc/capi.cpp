@@ -507,8 +507,14 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     int rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
     if (rc != SDRB_OK) return rc;
+    const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+    if (rowwise && a->n_rows != b->n_rows) {
+        set_error("row-wise evaluation needs batches of equal length (%llu vs %llu rows)",
+                  (unsigned long long)a->n_rows, (unsigned long long)b->n_rows);
+        return SDRB_ERR_INVALID_ARG;
+    }
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
-    if (!out || ld_out < b->n_rows) {
+    if (!out || (!rowwise && ld_out < b->n_rows)) {
         set_error("sdrb_size_op: out is null or ld_out (%llu) < rows of b (%llu)",
                   (unsigned long long)ld_out, (unsigned long long)b->n_rows);
         return SDRB_ERR_INVALID_ARG;
@@ -525,6 +531,7 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rowwise) return launch_size_merge(a, b, op, swap, out, ld_out, true, s);
     if (flags & SDRB_FLAG_FORCE_POPCOUNT) {
         if (!id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
             set_error("popcount kernel requested but not applicable to these batches/op");
@@ -539,7 +546,7 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
             return launch_size_popcount(a, b, op, swap, out, ld_out, s);
         if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
     }
-    return launch_size_merge(a, b, op, swap, out, ld_out, s);
+    return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
 }
 
 int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
@@ -603,14 +610,20 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
         set_error("sdrb_elem_op_count: null output");
         return SDRB_ERR_INVALID_ARG;
     }
-    const uint64_t pairs = a->n_rows * b->n_rows;
+    const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+    if (rowwise && a->n_rows != b->n_rows) {
+        set_error("row-wise evaluation needs batches of equal length (%llu vs %llu rows)",
+                  (unsigned long long)a->n_rows, (unsigned long long)b->n_rows);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const uint64_t pairs = rowwise ? b->n_rows : a->n_rows * b->n_rows;
     if (pairs >= 0xFFFFFFFFull) {
         set_error("too many pairs for one call (%llu)", (unsigned long long)pairs);
         return SDRB_ERR_OVERFLOW;
     }
     // an upper bound of the total keeps the 32-bit scan exact
     const bool swap_sides = (flags & SDRB_FLAG_SWAP) != 0;
-    const uint64_t from_a = a->nnz * b->n_rows, from_b = b->nnz * a->n_rows;
+    const uint64_t from_a = rowwise ? a->nnz : a->nnz * b->n_rows, from_b = rowwise ? b->nnz : b->nnz * a->n_rows;
     uint64_t bound;
     if (op == SDRB_OP_AND) bound = from_a < from_b ? from_a : from_b;
     else if (op == SDRB_OP_RM) bound = swap_sides ? from_b : from_a;
@@ -627,7 +640,7 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (pairs) {
-        rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE), out_offsets,
+        rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE), out_offsets,
                           b->n_rows, stream);
         if (rc != SDRB_OK) return rc;
     }
@@ -648,6 +661,11 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
     if (rc != SDRB_OK) return rc;
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
     const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+    if (rowwise && a->n_rows != b->n_rows) {
+        set_error("row-wise evaluation needs batches of equal length");
+        return SDRB_ERR_INVALID_ARG;
+    }
     const sdrb_batch* self = swap ? b : a;
     if (!out_offsets || !out_ids || (self->data_kind == SDRB_DATA_UNIT && !out_data)) {
         set_error("sdrb_elem_op_fill: null output (UnitData results need out_data)");
@@ -659,12 +677,12 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!(flags & SDRB_FLAG_FORCE_MERGE)) {
+    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise) {
         if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
         if (unit_table_fill_applicable(a, b, op, swap))
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }
-    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids, out_data, s);
+    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids, out_data, rowwise, s);
 }
 
 int sdrb_malloc(int device, size_t bytes, void** ptr) {

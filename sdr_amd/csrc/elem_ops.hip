@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
     const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
     const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
     const uint32_t* __restrict__ out_off, int32_t* __restrict__ out_ids,
-    float* __restrict__ out_data) {
+    float* __restrict__ out_data, uint32_t rowwise) {
     constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
     constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
     constexpr bool KEEP_THIS_ONLY = OP != SDRB_OP_AND;
@@ -100,12 +100,13 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
     const int32_t* bi = b_ids + b_beg;
     const float* bd = B_UNIT ? b_data + b_beg : nullptr;
 
-    for (uint64_t i = blockIdx.y; i < na; i += gridDim.y) {
+    // all pairs, or row-wise: row j of A only (result j)
+    for (uint64_t i = rowwise ? j : blockIdx.y; i < na; i += rowwise ? na : gridDim.y) {
         const uint32_t a_beg = a_off[i];
         const uint32_t la = a_off[i + 1] - a_beg;
         const int32_t* ai = a_ids + a_beg;
         const float* ad = A_UNIT ? a_data + a_beg : nullptr;
-        uint32_t w = out_off[i * nb + j];
+        uint32_t w = out_off[rowwise ? j : i * nb + j];
         auto emit = [&](int32_t id, float d) {
             out_ids[w] = id;
             if constexpr (THIS_UNIT) out_data[w] = d;
@@ -160,16 +161,17 @@ struct FillArgs {
     const uint32_t* out_off;
     int32_t* out_ids;
     float* out_data;
+    bool rowwise;
     hipStream_t stream;
 };
 
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
 void launch(const FillArgs& g) {
     const uint32_t gx = (uint32_t)((g.b->n_rows + kBlock - 1) / kBlock);
-    const uint32_t gy = (uint32_t)(g.a->n_rows < 65535 ? g.a->n_rows : 65535);
+    const uint32_t gy = g.rowwise ? 1u : (uint32_t)(g.a->n_rows < 65535 ? g.a->n_rows : 65535);
     hipLaunchKernelGGL((k_elem_fill<OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
                        g.a->d_offsets, g.a->d_ids, g.a->d_data, g.a->n_rows, g.b->d_offsets,
-                       g.b->d_ids, g.b->d_data, g.b->n_rows, g.out_off, g.out_ids, g.out_data);
+                       g.b->d_ids, g.b->d_data, g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.rowwise ? 1u : 0u);
 }
 
 template <int OP, bool SWAP>
@@ -204,9 +206,9 @@ int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_
 }
 
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
-                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
+                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data, bool rowwise,
                      hipStream_t stream) {
-    FillArgs g{a, b, out_offsets, out_ids, out_data, stream};
+    FillArgs g{a, b, out_offsets, out_ids, out_data, rowwise, stream};
     switch (op) {
     case SDRB_OP_AND: launch_swap<SDRB_OP_AND>(g, swap); break;
     case SDRB_OP_OR: launch_swap<SDRB_OP_OR>(g, swap); break;

@@ -63,13 +63,14 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
                          uint32_t* out, uint64_t ld_out, hipStream_t stream);
 
 // size_merge.hip ------------------------------------------------------------------
+// rowwise: result j = A_j.op(B_j) for two batches of equal length, out[j]
 int launch_size_merge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
-                      uint32_t* out, uint64_t ld_out, hipStream_t stream);
+                      uint32_t* out, uint64_t ld_out, bool rowwise, hipStream_t stream);
 
 // elem_ops.hip --------------------------------------------------------------------
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream);
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
-                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
+                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data, bool rowwise,
                      hipStream_t stream);
 
 // elem_bitmap.hip ------------------------------------------------------------------

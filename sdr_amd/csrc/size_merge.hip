@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kBlock) void k_size_merge(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids,
     const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
     const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
-    uint32_t* __restrict__ out, uint64_t ld_out) {
+    uint32_t* __restrict__ out, uint64_t ld_out, uint32_t rowwise) {
     constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
     constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
     const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -29,7 +29,9 @@ __global__ __launch_bounds__(kBlock) void k_size_merge(
     const int32_t* bi = b_ids + b_beg;
     const float* bd = B_UNIT ? b_data + b_beg : nullptr;
 
-    for (uint64_t i = blockIdx.y; i < na; i += gridDim.y) {
+    // all pairs: this lane's row against every row of A the block column visits;
+    // row-wise: against row j of A only (result j)
+    for (uint64_t i = rowwise ? j : blockIdx.y; i < na; i += rowwise ? na : gridDim.y) {
         const uint32_t a_beg = a_off[i];
         const uint32_t la = a_off[i + 1] - a_beg;
         const int32_t* ai = a_ids + a_beg;
@@ -54,47 +56,47 @@ __global__ __launch_bounds__(kBlock) void k_size_merge(
         }
         const uint32_t l_this = SWAP ? lb : la;
         const uint32_t l_arg = SWAP ? la : lb;
-        out[i * ld_out + j] = size_from_counts<OP>(l_this, l_arg, m, k);
+        out[(rowwise ? 0 : i * ld_out) + j] = size_from_counts<OP>(l_this, l_arg, m, k);
     }
 }
 
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
-void launch(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out,
+void launch(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out, bool rowwise,
             hipStream_t stream) {
     const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
-    const uint32_t gy = (uint32_t)(a->n_rows < 65535 ? a->n_rows : 65535);
+    const uint32_t gy = rowwise ? 1u : (uint32_t)(a->n_rows < 65535 ? a->n_rows : 65535);
     hipLaunchKernelGGL((k_size_merge<OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, stream,
                        a->d_offsets, a->d_ids, a->d_data, a->n_rows, b->d_offsets, b->d_ids,
-                       b->d_data, b->n_rows, out, ld_out);
+                       b->d_data, b->n_rows, out, ld_out, rowwise ? 1u : 0u);
 }
 
 template <int OP, bool SWAP>
-void launch_kinds(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out,
+void launch_kinds(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out, bool rowwise,
                   hipStream_t stream) {
     const bool au = a->data_kind == SDRB_DATA_UNIT, bu = b->data_kind == SDRB_DATA_UNIT;
-    if (au && bu) launch<OP, SWAP, true, true>(a, b, out, ld_out, stream);
-    else if (au) launch<OP, SWAP, true, false>(a, b, out, ld_out, stream);
-    else if (bu) launch<OP, SWAP, false, true>(a, b, out, ld_out, stream);
-    else launch<OP, SWAP, false, false>(a, b, out, ld_out, stream);
+    if (au && bu) launch<OP, SWAP, true, true>(a, b, out, ld_out, rowwise, stream);
+    else if (au) launch<OP, SWAP, true, false>(a, b, out, ld_out, rowwise, stream);
+    else if (bu) launch<OP, SWAP, false, true>(a, b, out, ld_out, rowwise, stream);
+    else launch<OP, SWAP, false, false>(a, b, out, ld_out, rowwise, stream);
 }
 
 template <int OP>
 void launch_swap(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_t* out,
-                 uint64_t ld_out, hipStream_t stream) {
-    if (swap) launch_kinds<OP, true>(a, b, out, ld_out, stream);
-    else launch_kinds<OP, false>(a, b, out, ld_out, stream);
+                 uint64_t ld_out, bool rowwise, hipStream_t stream) {
+    if (swap) launch_kinds<OP, true>(a, b, out, ld_out, rowwise, stream);
+    else launch_kinds<OP, false>(a, b, out, ld_out, rowwise, stream);
 }
 
 }  // namespace
 
 int launch_size_merge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
-                      uint64_t ld_out, hipStream_t stream) {
+                      uint64_t ld_out, bool rowwise, hipStream_t stream) {
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
     switch (op) {
-    case SDRB_OP_AND: launch_swap<SDRB_OP_AND>(a, b, swap, out, ld_out, stream); break;
-    case SDRB_OP_OR: launch_swap<SDRB_OP_OR>(a, b, swap, out, ld_out, stream); break;
-    case SDRB_OP_XOR: launch_swap<SDRB_OP_XOR>(a, b, swap, out, ld_out, stream); break;
-    case SDRB_OP_RM: launch_swap<SDRB_OP_RM>(a, b, swap, out, ld_out, stream); break;
+    case SDRB_OP_AND: launch_swap<SDRB_OP_AND>(a, b, swap, out, ld_out, rowwise, stream); break;
+    case SDRB_OP_OR: launch_swap<SDRB_OP_OR>(a, b, swap, out, ld_out, rowwise, stream); break;
+    case SDRB_OP_XOR: launch_swap<SDRB_OP_XOR>(a, b, swap, out, ld_out, rowwise, stream); break;
+    case SDRB_OP_RM: launch_swap<SDRB_OP_RM>(a, b, swap, out, ld_out, rowwise, stream); break;
     default: set_error("unknown op %d", op); return SDRB_ERR_INVALID_ARG;
     }
     SDRB_HIP(hipGetLastError());

@@ -340,3 +340,76 @@ def test_batch_from_database_file_equals_batch_from_arrays(tmp_path, with_data):
         ids_only = csrfile.upload_rows(path, lo, hi, payloads=False)
         want = SDRBatch.from_csr(s_off, s_ids, None, width=2048)
         assert torch.equal(q.ands(ids_only), q.ands(want))
+
+
+def _repeat_rows(b: Batch, rows):
+    """The listed rows of a host batch, in that order, as a new host batch."""
+    off, ids, data = [0], [], []
+    for r in rows:
+        r_ids, r_data = b.row(r)
+        ids.append(r_ids)
+        if r_data is not None:
+            data.append(r_data)
+        off.append(off[-1] + len(r_ids))
+    return Batch(np.asarray(off, np.uint64), np.concatenate(ids) if ids else np.zeros(0, np.int32),
+                 np.concatenate(data) if data else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_rowwise_and_inplace_ops_vs_inplace_golden(golden, name):
+    """Row-wise evaluation (result j = A_j.op(B_j)) and the in-place batch ops built on it against the
+    fixture the reference's andi/ori/xori/rmi generated (lengths and content digests)."""
+    g = golden("inplace.npz")
+    n = 32
+    t, a = fuzz_pair(n, name, int(g["seed"]))
+    rows_i = list(range(0, n, 3))
+    pairs = [(i, j) for i in rows_i for j in range(n)]
+    tt = _repeat_rows(t, [i for i, _ in pairs])
+    aa = _repeat_rows(a, [j for _, j in pairs])
+    d_a = dev(aa)
+    for op, (sname, ename) in OPS.items():
+        want_len = np.array([g[f"{name}_len{op}"][i, j] for i, j in pairs], dtype=np.int64)
+        want_dig = np.array([g[f"{name}_digest{op}"][i, j] for i, j in pairs], dtype=np.uint32)
+        d_t = dev(tt)
+        assert np.array_equal(d_t.rowwise_size(sname, d_a).cpu().numpy().astype(np.int64), want_len), sname
+        off, ids, data = d_t.rowwise_elem(ename, d_a).to_host()
+        assert np.array_equal(np.diff(off).astype(np.int64), want_len), ename
+        assert np.array_equal(util.pair_digests(off, ids, data), want_dig), ename
+        # in place: the batch itself now holds the results
+        getattr(d_t, ename[:-1] + "i")(d_a)
+        assert d_t.n_rows == len(pairs) and d_t.nnz == int(want_len.sum())
+        w = d_t.to_wire().cpu().numpy()
+        got_off = w[: len(pairs) + 1].view(np.uint32).astype(np.uint64)
+        got_ids = w[len(pairs) + 1: len(pairs) + 1 + d_t.nnz]
+        got_data = w[len(pairs) + 1 + d_t.nnz:].view(np.float32) if tt.data is not None else None
+        assert np.array_equal(util.pair_digests(got_off, got_ids, got_data), want_dig), ename + " in place"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["E", "U"])
+def test_inplace_aliasing_a_op_a(golden, kind):
+    """a.andi(a), a.ori(a), a.xori(a), a.rmi(a) are legal in the reference (src/test.cpp:241-272)."""
+    g = golden("inplace.npz")
+    n = 32
+    u = Batch(*util.fuzz_universe(n, int(g["seed"]) if kind == "U" else None))
+    for op, (_, ename) in OPS.items():
+        d_u = dev(u)
+        getattr(d_u, ename[:-1] + "i")(d_u)
+        w = d_u.to_wire().cpu().numpy()
+        got_off = w[: n + 1].view(np.uint32).astype(np.uint64)
+        got_ids = w[n + 1: n + 1 + d_u.nnz]
+        got_data = w[n + 1 + d_u.nnz:].view(np.float32) if u.data is not None else None
+        assert np.array_equal(np.diff(got_off), g[f"alias_{kind}_len{op}"].astype(np.uint64)), ename
+        assert np.array_equal(util.pair_digests(got_off, got_ids, got_data), g[f"alias_{kind}_digest{op}"]), ename
+
+
+@pytest.mark.gpu
+def test_rowwise_needs_equal_lengths():
+    rng = np.random.default_rng(4)
+    a = SDRBatch.from_csr(*util.ragged_rows(rng, 5, 100, 10), width=100)
+    b = SDRBatch.from_csr(*util.ragged_rows(rng, 6, 100, 10), width=100)
+    with pytest.raises(sdr_amd.SdrbError):
+        a.rowwise_size("ands", b)
+    with pytest.raises(ValueError):
+        a.andi(b)

@@ -61,6 +61,22 @@ def main():
                 "elem_GBps": round((in_bytes + out_bytes) / ms_e / 1e6, 1),
                 "pair_ops_per_s": round(nq * nd / (ms_e * 1e-3), 0)}), flush=True)
             del res, counts
+    if "inner" in args.cases:
+        # sparse dot products (SDR::inner / diff_mul): 4096 x rows pairs at 2048/40 with float payloads,
+        # and the matrix x vector shape (1 x rows)
+        width, active = 2048, 40
+        d_off, d_ids, _ = sdr_amd.synth_csr(1, 0, args.rows, width, active)
+        rng = np.random.default_rng(0)
+        d = SDRBatch.from_csr(d_off, d_ids, rng.standard_normal(d_ids.size).astype(np.float32), width=width, kind="arith")
+        for nq in (1, 4096):
+            q_off, q_ids, _ = sdr_amd.synth_csr(2, 0, nq, width, active)
+            q = SDRBatch.from_csr(q_off, q_ids, rng.standard_normal(q_ids.size).astype(np.float32), width=width, kind="arith")
+            out = torch.empty((nq, args.rows), dtype=torch.float32, device="cuda:0")
+            ms, _ = timed(lambda: q.inner(d, out=out), args.reps)
+            nbytes = args.rows * (8 * active + 4) + nq * (8 * active + 4) + nq * args.rows * 4
+            print(json.dumps({"case": "inner", "queries": nq, "rows": args.rows, "width": width, "active": active,
+                              "ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1),
+                              "pair_ops_per_s": round(nq * args.rows / (ms * 1e-3), 0)}), flush=True)
 
 
 if __name__ == "__main__":
