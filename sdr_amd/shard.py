@@ -132,6 +132,9 @@ class HipEngine:
     def size_op(self, name: str, queries, shard, out=None):
         return getattr(queries, name)(shard, out=out)
 
+    def elem_op(self, name: str, queries, shard):
+        return getattr(queries, name)(shard)
+
     def allpairs_topk(self, rows, candidates, k, exclude_offset):
         return rows.allpairs_topk(candidates, k, exclude_offset=exclude_offset)
 
@@ -296,6 +299,25 @@ class ShardedDatabase:
         """``name`` in {ands, ors, xors, rms}: counts of ``queries`` x this rank's rows, i.e.
         columns [row_lo, row_hi) of the global result.  No communication."""
         return self.engine.size_op(name, queries, self.shard, out=out)
+
+    def elem_op(self, name: str, queries):
+        """``name`` in {ande, ore, xore, rme}: the element results of ``queries`` x this rank's rows
+        stay on this rank (CSR over the local pairs).  Only the shards' element totals travel
+        (one int64 per rank), giving the position of this shard's elements in the global result:
+        returns ``(local_result, global_element_offset, global_element_total)``."""
+        import torch
+        import torch.distributed as dist
+
+        res = self.engine.elem_op(name, queries, self.shard)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return res, 0, int(res.total)
+        rank = dist.get_rank(self.group)
+        mine = torch.tensor([int(res.total)], dtype=torch.int64, device=self.engine.torch_device())
+        totals = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(totals, mine, group=self.group)
+        totals = [int(t) for t in totals]
+        return res, sum(totals[:rank]), sum(totals)
 
     def gather_counts(self, local_counts):
         """All-gathers the per-shard count slabs into the full [Q][N] matrix on every rank.

@@ -67,6 +67,12 @@ class OracleEngine:
             out_c[i, : len(order)], out_r[i, : len(order)] = counts[i][order], order
         return torch.from_numpy(out_c), torch.from_numpy(out_r)
 
+    def elem_op(self, name, queries, shard):
+        import oracle
+        from types import SimpleNamespace
+        off, ids, data = oracle.port().elem_op({"ande": 0, "ore": 1, "xore": 2, "rme": 3}[name], queries, shard)
+        return SimpleNamespace(offsets=off, ids=ids, data=data, total=int(off[-1]))
+
     def size_op(self, name, queries, shard, out=None):
         import oracle
         return torch.from_numpy(oracle.port().size_op(OPS[name], queries, shard).astype(np.int32))
@@ -116,6 +122,9 @@ def _worker(rank, world, port, with_data, n_rows, results, tmpdir):
         assert wire.plan.words == wire.tensor.numel()
         again = db.broadcast_packed(wire if rank == 0 else None, wire.plan, src=0)
         assert np.array_equal(db.gather_counts(db.size_op("xors", again)).numpy(), out["xors"])
+        # element ops: results stay sharded, only the totals travel
+        res, elem_lo, elem_total = db.elem_op("xore", queries)
+        results[f"xore_{rank}"] = (db.row_lo, db.row_hi, res.offsets, res.ids, elem_lo, elem_total)
         # all-pairs: the shards are all-gathered into the whole database on every rank
         whole = db.gather_database()
         w_off, w_ids, w_data = whole.csr()
@@ -148,6 +157,19 @@ def test_two_rank_sharded_size_ops(with_data, n_rows, tmp_path):
         want = oracle.port().size_op(op, q, d)
         assert np.array_equal(results[name].view(np.uint32), want), name
     assert np.array_equal(results["rank1_ands"], results["ands"])
+    # sharded element op: every shard's CSR equals the oracle on its columns, and the element
+    # offsets tile the global total
+    x_off, x_ids, _ = oracle.port().elem_op(2, q, d)
+    seen = 0
+    for rank in range(world):
+        lo, hi, off, ids, elem_lo, elem_total = results[f"xore_{rank}"]
+        assert elem_lo == seen and elem_total == sum(len(results[f"xore_{r}"][3]) for r in range(world))
+        seen += len(ids)
+        for i in range(9):
+            for j in range(lo, hi):
+                want = x_ids[int(x_off[i * n_rows + j]):int(x_off[i * n_rows + j + 1])]
+                k = i * (hi - lo) + (j - lo)
+                assert np.array_equal(ids[int(off[k]):int(off[k + 1])], want)
     # all-pairs top-4 of every row over the whole database, self match excluded
     self_counts = oracle.port().size_op(0, oracle.Batch(d.csr()[0], d.csr()[1], None),
                                         oracle.Batch(d.csr()[0], d.csr()[1], None)).astype(np.int64)
