@@ -65,6 +65,8 @@ extern "C" {
                                        every pair; outputs have one entry per row (out[j], offsets[n+1]).  This is the
                                        batched form of the in-place ops andi/ori/xori/rmi (SDR.hpp:1027-1081,1239-1292,
                                        1366-1513), whose results equal those of the element ops */
+#define SDRB_FLAG_FORCE_ROWTABLE 64u /* size ops: use the one-row-of-A position-table kernel where the 64-row mask-table
+                                       kernel would be chosen (tests and experiments) */
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;

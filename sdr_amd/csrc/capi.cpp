@@ -544,6 +544,9 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         // rows too long for the bit-sliced kernel: the popcount kernel's cost does not depend on row length
         if (id_only(a, b, op, swap) && popcount_applicable(a, b))
             return launch_size_popcount(a, b, op, swap, out, ld_out, s);
+        // payloads or long rows: with several rows of A the 64-row mask table reads B once for all of them
+        if (!(flags & SDRB_FLAG_FORCE_ROWTABLE) && a->n_rows >= 4 && mask_table_applicable(a, b))
+            return launch_size_mask_table(a, b, op, swap, out, ld_out, s);
         if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
     }
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
@@ -640,7 +643,7 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (pairs) {
-        rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE), out_offsets,
+        rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE | SDRB_FLAG_FORCE_ROWTABLE), out_offsets,
                           b->n_rows, stream);
         if (rc != SDRB_OK) return rc;
     }
@@ -679,6 +682,8 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise) {
         if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
+        if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && a->n_rows >= 4 && mask_table_applicable(a, b))
+            return launch_elem_mask_table(a, b, swap, out_offsets, out_ids, out_data, s);
         if (unit_table_fill_applicable(a, b, op, swap))
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }

@@ -1,0 +1,362 @@
+// Query-mask table kernel for the size operations on long rows and/or payloads (e.g. UnitData rows
+// of 328 ids over a width of 16384): the long batch B is read from HBM ONCE for 64 rows of A.
+//
+// The reference finds the common ids of a pair with andv (SDR.hpp:958-997) and hands each match to
+// the op's size visitor (SDR.hpp:1087-1091, 1298-1301, 1428-1431, 1572-1574).  Here a block keeps,
+// for a tile of 64 rows of A,
+//
+//     mask[w] (uint64, LDS)  bit q set  <=>  row 64*tile + q of A contains id w     (8 B x width)
+//
+// and streams rows of B, one wave per row, one lane per element: a lane looks up mask[id] and
+// visits its set bits -- each one is an id match of the pair (q, j).  The payload of A for that
+// match comes from a dense value matrix val[q][w] (global, L2-resident, built per call), the
+// payload rule of the op is evaluated (single IEEE operations, sdrb_device.h) and the pair's
+// counters in LDS get  (1 << 16) | kept  added.  After 64 rows of B the 64 x 64 counter tile is
+// turned into sizes and written as coalesced rows.  B is read once per 64 rows of A instead of
+// once per row; the table is rebuilt only when the block moves to another tile of A.
+#include "sdrb_device.h"
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+constexpr int kBlock = 1024;
+constexpr int kWaves = kBlock / 64;
+constexpr int kGroup = 64;                       // rows of B per counter tile
+constexpr int kRowsPerWave = kGroup / kWaves;    // 4
+constexpr int kTile = 64;                        // rows of A per mask table
+
+// How a match's payload decides whether it is kept; `t` is the payload of `this`
+// (same classification as unit_table.hip).
+enum Math { kKeepAll, kDropAll, kSelfA, kSelfB, kMul, kAbsDiff, kRmulA, kRmulB };
+
+template <int MATH>
+__device__ __forceinline__ bool match_kept_by(float va, float vb, float& d) {
+    d = 0.0f;
+    if constexpr (MATH == kKeepAll) return true;
+    else if constexpr (MATH == kDropAll) return false;
+    else {
+        if constexpr (MATH == kSelfA) d = va;
+        else if constexpr (MATH == kSelfB) d = vb;
+        else if constexpr (MATH == kMul) d = va * vb;
+        else if constexpr (MATH == kAbsDiff) d = fabsf(va - vb);
+        else if constexpr (MATH == kRmulA) { const float om = 1.0f - vb; d = va * om; }
+        else { const float om = 1.0f - va; d = vb * om; }
+        return unit_relevant(d);
+    }
+}
+
+__device__ __forceinline__ uint32_t size_of(int op, uint32_t l_this, uint32_t l_arg, uint32_t m, uint32_t k) {
+    if (op == SDRB_OP_AND) return k;
+    if (op == SDRB_OP_OR) return l_this + l_arg - m;
+    if (op == SDRB_OP_XOR) return l_this + l_arg - 2 * m + k;
+    return l_this - m + k;
+}
+
+// dense payload matrix of A: val[i][w] = payload of id w in row i (only read where mask says so)
+__global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restrict__ a_off,
+                                                        const int32_t* __restrict__ a_ids,
+                                                        const float* __restrict__ a_val, uint32_t width,
+                                                        float* __restrict__ val) {
+    const uint64_t i = blockIdx.x;
+    const uint32_t beg = a_off[i], len = a_off[i + 1] - beg;
+    for (uint32_t k = threadIdx.x; k < len; k += 64) {
+        const uint32_t id = (uint32_t)a_ids[beg + k];
+        if (id < width) val[i * width + id] = a_val[beg + k];
+    }
+}
+
+// FILL == false: size ops (counters -> sizes).  FILL == true: ande -- the counter tile starts at the
+// pairs' output offsets and every kept match takes the next slot of its pair; slots of one pair are
+// claimed by concurrent lanes, so a pair's elements are put in id order afterwards (k_sort_pairs).
+template <int MATH, int NIT, bool FILL>
+__global__ __launch_bounds__(kBlock) void k_size_mask_table(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val_dense,
+    uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
+    const float* __restrict__ b_data, uint32_t nb, uint32_t width, int op, uint32_t swap,
+    uint32_t* __restrict__ out, uint64_t ld_out, const uint32_t* __restrict__ out_off,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_data) {
+    constexpr bool NEED_A = MATH == kSelfA || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
+    constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
+    constexpr int IT = NIT == 0 ? 1 : NIT;
+    // LDS: mask[width + 1] (mask[width] = 0, the sentinel), cnt[64][64], la[64], lb[64]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(lds_raw);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(mask + width + 1);
+    uint32_t* la = cnt + kTile * kGroup;
+    uint32_t* lb = la + kTile;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.y, i0 = tile * kTile;
+    const uint32_t rows_a = na - i0 < (uint32_t)kTile ? na - i0 : (uint32_t)kTile;
+
+    for (uint32_t w = tid; w < width + 1; w += kBlock) mask[w] = 0;
+    for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) cnt[e] = 0;
+    if (tid < kTile) la[tid] = tid < rows_a ? a_off[i0 + tid + 1] - a_off[i0 + tid] : 0u;
+    __syncthreads();
+    // wave w sets the bits of rows w, w + 16, ... of the tile
+    for (uint32_t q = wave; q < rows_a; q += kWaves) {
+        const uint32_t beg = a_off[i0 + q], len = a_off[i0 + q + 1] - beg;
+        for (uint32_t k = lane; k < len; k += 64) {
+            const uint32_t id = (uint32_t)a_ids[beg + k];
+            if (id < width) atomicOr(&mask[id], 1ull << q);   // ids outside B's width never match
+        }
+    }
+    __syncthreads();
+
+    const float* val_tile = NEED_A ? a_val_dense + (uint64_t)i0 * width : nullptr;
+    const uint32_t n_groups = (nb + kGroup - 1) / kGroup;
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t j0 = g * kGroup;
+        if constexpr (FILL) {   // the tile of output positions of this group's pairs
+            for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) {
+                const uint32_t q = e / kGroup, jl = e % kGroup;
+                if (q < rows_a && j0 + jl < nb) cnt[e] = out_off[(uint64_t)(i0 + q) * nb + j0 + jl];
+            }
+            __syncthreads();
+        }
+        // Rows of up to 64*NIT elements travel HBM -> registers whole (bounds-checked buffer loads, all
+        // chunks issued back to back), and the next row is requested before the current one is
+        // processed, so a wave keeps two rows in flight; NIT == 0 streams longer rows chunk by chunk.
+        uint32_t cur_id[IT], nxt_id[IT];
+        float cur_v[IT], nxt_v[IT];
+        uint32_t cur_len = 0, nxt_len = 0;
+        auto request = [&](uint32_t jl, uint32_t (&rid)[IT], float (&rv)[IT], uint32_t& rlen) {
+            const uint32_t j = j0 + jl;
+            const uint32_t beg = j < nb ? b_off[j] : 0u;
+            rlen = j < nb ? b_off[j + 1] - beg : 0u;
+            if constexpr (NIT > 0) {
+                __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<int32_t*>(b_ids) + beg, 0, (int)(rlen * 4u), 0x00020000);
+                __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(b_data) + (NEED_B ? beg : 0u), 0, NEED_B ? (int)(rlen * 4u) : 0, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const uint32_t e = it * 64 + lane;
+                    rid[it] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ids_rsrc, (int)(e * 4u), 0, 0);
+                    rv[it] = 0.0f;
+                    if constexpr (NEED_B)
+                        rv[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, (int)(e * 4u), 0, 0));
+                }
+            }
+        };
+        auto visit = [&](uint32_t id, float vb, uint32_t jl) {
+            unsigned long long m = mask[id];
+            // every set bit is an id match of pair (q, j); four at a time so that the payload
+            // gathers of a lane (L2 latency) are in flight together
+            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+                uint32_t q[4];
+                bool has[4];
+                float va[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    has[u] = m != 0;
+                    q[u] = has[u] ? (uint32_t)__builtin_ctzll(m) : 0u;
+                    m &= m - 1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    va[u] = 0.0f;
+                    if constexpr (NEED_A) {
+                        if (has[u]) va[u] = val_tile[(uint64_t)q[u] * width + id];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (has[u]) {
+                        float d;
+                        const bool kept = match_kept_by<MATH>(va[u], vb, d);
+                        if constexpr (!FILL) {
+                            atomicAdd(&cnt[q[u] * kGroup + jl], 0x10000u | (kept ? 1u : 0u));
+                        } else if (kept) {
+                            const uint32_t slot = atomicAdd(&cnt[q[u] * kGroup + jl], 1u);
+                            out_ids[slot] = (int32_t)id;
+                            if constexpr (MATH != kKeepAll) out_data[slot] = d;
+                        }
+                    }
+                }
+            }
+        };
+        request(wave * kRowsPerWave, cur_id, cur_v, cur_len);
+#pragma unroll 1
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const uint32_t jl = wave * kRowsPerWave + r;
+            if (r + 1 < kRowsPerWave) request(jl + 1, nxt_id, nxt_v, nxt_len);
+            if (lane == 0) lb[jl] = cur_len;
+            if constexpr (NIT > 0) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    // lanes past the row's end read nothing: give them the sentinel id (mask 0)
+                    const uint32_t id = (uint32_t)(it * 64) + lane < cur_len ? cur_id[it] : width;
+                    if ((uint32_t)(it * 64) < cur_len) visit(id, cur_v[it], jl);
+                }
+            } else {
+                const uint32_t j = j0 + jl;
+                const uint32_t beg = j < nb ? b_off[j] : 0u;
+                for (uint32_t e0 = 0; e0 < cur_len; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    uint32_t id = width;
+                    float vb = 0.0f;
+                    if (e < cur_len) {
+                        id = (uint32_t)b_ids[beg + e];
+                        if constexpr (NEED_B) vb = b_data[beg + e];
+                    }
+                    visit(id, vb, jl);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                cur_id[it] = nxt_id[it];
+                cur_v[it] = nxt_v[it];
+            }
+            cur_len = nxt_len;
+        }
+        __syncthreads();
+        // counters -> sizes, one coalesced 256-byte row segment per wave instruction; reset the tile
+        for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) {
+            if constexpr (FILL) break;
+            const uint32_t q = e / kGroup, jl = e % kGroup;
+            const uint32_t c = cnt[e];
+            cnt[e] = 0;
+            if (q < rows_a && j0 + jl < nb) {
+                const uint32_t l_this = swap ? lb[jl] : la[q], l_arg = swap ? la[q] : lb[jl];
+                out[(uint64_t)(i0 + q) * ld_out + j0 + jl] = size_of(op, l_this, l_arg, c >> 16, c & 0xffffu);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one thread per pair: insertion sort of the pair's few elements by id (payloads travel along)
+__global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__ off, uint64_t n_pairs,
+                                                    int32_t* __restrict__ ids, float* __restrict__ data) {
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t lo = off[p], hi = off[p + 1];
+    for (uint32_t k = lo + 1; k < hi; ++k) {
+        const int32_t id = ids[k];
+        const float d = data ? data[k] : 0.0f;
+        uint32_t s = k;
+        while (s > lo && ids[s - 1] > id) {
+            ids[s] = ids[s - 1];
+            if (data) data[s] = data[s - 1];
+            --s;
+        }
+        if (s != k) {
+            ids[s] = id;
+            if (data) data[s] = d;
+        }
+    }
+}
+
+int pick_math(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
+    const bool au = a->data_kind == SDRB_DATA_UNIT, bu = b->data_kind == SDRB_DATA_UNIT;
+    const bool this_unit = swap ? bu : au, arg_unit = swap ? au : bu;
+    if (op == SDRB_OP_OR) return kKeepAll;
+    if (!this_unit) return op == SDRB_OP_AND ? kKeepAll : kDropAll;
+    if (!arg_unit) return swap ? kSelfB : kSelfA;
+    if (op == SDRB_OP_AND) return kMul;
+    if (op == SDRB_OP_XOR) return kAbsDiff;
+    return swap ? kRmulB : kRmulA;
+}
+
+size_t lds_bytes(uint32_t width) {
+    return (size_t)(width + 1) * 8 + (size_t)kTile * kGroup * 4 + 2 * kTile * 4;
+}
+
+}  // namespace
+
+bool mask_table_applicable(const sdrb_batch* a, const sdrb_batch* b) {
+    // the mask table and the counter tile must fit the 160 KiB of LDS; counters hold row lengths in 16 bits
+    return b->width > 0 && lds_bytes((uint32_t)b->width) <= 160 * 1024 - 512 && a->max_row_len < 65536 &&
+           b->max_row_len < 65536 && (a->n_rows + kTile - 1) / kTile <= 65535;
+}
+
+namespace {
+
+int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, bool fill, uint32_t* out,
+                   uint64_t ld_out, const uint32_t* out_off, int32_t* out_ids, float* out_data, hipStream_t stream) {
+    const uint32_t width = (uint32_t)b->width, na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
+    const int math = pick_math(a, b, op, swap);
+    const bool need_a = math == kSelfA || math == kMul || math == kAbsDiff || math == kRmulA || math == kRmulB;
+    float* dense = nullptr;
+    if (need_a) {
+        const size_t bytes = (size_t)na * width * sizeof(float);
+        dense = static_cast<float*>(workspace(b->device, 6, bytes));
+        if (!dense) return SDRB_ERR_HIP;
+        // only entries the mask points at are ever read, so the matrix needs no clearing
+        hipLaunchKernelGGL(k_scatter_values, dim3(na), dim3(64), 0, stream, a->d_offsets, a->d_ids, a->d_data, width,
+                           dense);
+        SDRB_HIP(hipGetLastError());
+    }
+    const size_t lds = lds_bytes(width);
+    const uint32_t tiles = (na + kTile - 1) / kTile;
+    const uint32_t groups = (nb + kGroup - 1) / kGroup;
+    // one or two resident blocks per CU, shared among the tiles of A
+    const uint32_t per_cu = lds <= 80 * 1024 - 256 ? 2u : 1u;
+    uint32_t gx = (256u * per_cu + tiles - 1) / tiles;
+    if (gx > groups) gx = groups;
+    if (gx == 0) gx = 1;
+    const dim3 grid(gx, tiles);
+    const uint32_t len = b->max_row_len;
+    const int nit = len <= 64 ? 1 : len <= 128 ? 2 : len <= 384 ? 6 : 0;
+#define SDRB_MT_LAUNCH_NF(M, N, F)                                                                                   \
+    do {                                                                                                             \
+        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_size_mask_table<M, N, F>),                     \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+        hipLaunchKernelGGL((k_size_mask_table<M, N, F>), grid, dim3(kBlock), lds, stream, a->d_offsets, a->d_ids,    \
+                           dense, na, b->d_offsets, b->d_ids, b->d_data, nb, width, op, swap ? 1u : 0u, out, ld_out, \
+                           out_off, out_ids, out_data);                                                              \
+    } while (0)
+#define SDRB_MT_LAUNCH_N(M, N)               \
+    do {                                     \
+        if (fill) SDRB_MT_LAUNCH_NF(M, N, true); \
+        else SDRB_MT_LAUNCH_NF(M, N, false); \
+    } while (0)
+#define SDRB_MT_LAUNCH(M)                          \
+    do {                                           \
+        if (nit == 1) SDRB_MT_LAUNCH_N(M, 1);      \
+        else if (nit == 2) SDRB_MT_LAUNCH_N(M, 2); \
+        else if (nit == 6) SDRB_MT_LAUNCH_N(M, 6); \
+        else SDRB_MT_LAUNCH_N(M, 0);               \
+    } while (0)
+    switch (math) {
+    case kKeepAll: SDRB_MT_LAUNCH(kKeepAll); break;
+    case kDropAll: SDRB_MT_LAUNCH(kDropAll); break;
+    case kSelfA: SDRB_MT_LAUNCH(kSelfA); break;
+    case kSelfB: SDRB_MT_LAUNCH(kSelfB); break;
+    case kMul: SDRB_MT_LAUNCH(kMul); break;
+    case kAbsDiff: SDRB_MT_LAUNCH(kAbsDiff); break;
+    case kRmulA: SDRB_MT_LAUNCH(kRmulA); break;
+    default: SDRB_MT_LAUNCH(kRmulB); break;
+    }
+#undef SDRB_MT_LAUNCH
+#undef SDRB_MT_LAUNCH_N
+#undef SDRB_MT_LAUNCH_NF
+    SDRB_HIP(hipGetLastError());
+    if (fill) {
+        const uint64_t pairs = (uint64_t)na * nb;
+        hipLaunchKernelGGL(k_sort_pairs, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, stream, out_off, pairs,
+                           out_ids, math == kKeepAll ? nullptr : out_data);
+        SDRB_HIP(hipGetLastError());
+    }
+    return SDRB_OK;
+}
+
+}  // namespace
+
+int launch_size_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
+                           uint64_t ld_out, hipStream_t stream) {
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    return run_mask_table(a, b, op, swap, false, out, ld_out, nullptr, nullptr, nullptr, stream);
+}
+
+// ande for every pair: the kept matches of a pair, (id, combined payload), in id order
+int launch_elem_mask_table(const sdrb_batch* a, const sdrb_batch* b, bool swap, const uint32_t* out_offsets,
+                           int32_t* out_ids, float* out_data, hipStream_t stream) {
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    return run_mask_table(a, b, SDRB_OP_AND, swap, true, nullptr, 0, out_offsets, out_ids, out_data, stream);
+}
+
+}  // namespace sdrb

@@ -36,7 +36,8 @@ void set_error(const char* fmt, ...);
 
 // Per-device scratch that grows on demand and lives until process exit.
 // slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
-// slot 4: partial top-k lists; slot 5: interleaved value table of A (dot products).
+// slot 4: partial top-k lists; slot 5: interleaved value table of A (dot products);
+// slot 6: dense payload matrix of A (mask-table kernel).
 void* workspace(int device, int slot, size_t bytes);
 
 #define SDRB_HIP(call)                                                                   \
@@ -104,6 +105,14 @@ int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t 
 int launch_merge_topk(const int* partial, uint32_t na, uint32_t splits, uint32_t lists_per_split,
                       uint64_t rows_per_split, uint32_t k, uint32_t* out_counts, int32_t* out_rows,
                       hipStream_t stream);
+
+// mask_table.hip ---------------------------------------------------------------------------
+// Size ops with a 64-row query-mask table in LDS: B is read once per 64 rows of A (width <= ~17800).
+bool mask_table_applicable(const sdrb_batch* a, const sdrb_batch* b);
+int launch_size_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                           uint32_t* out, uint64_t ld_out, hipStream_t stream);
+int launch_elem_mask_table(const sdrb_batch* a, const sdrb_batch* b, bool swap, const uint32_t* out_offsets,
+                           int32_t* out_ids, float* out_data, hipStream_t stream);
 
 // inner.hip --------------------------------------------------------------------------------
 // Sparse dot products of ArithData<float> rows for every pair (SDR::inner, SDR.hpp:1682-1692).

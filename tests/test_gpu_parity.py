@@ -257,10 +257,13 @@ def test_table_kernels_with_declared_width_vs_oracle(name, width, len_a, len_b):
         want = oracle.port().size_op(op, t, a)
         assert np.array_equal(gpu_sizes(op, dt, da), want)
         assert np.array_equal(gpu_sizes(op, dt, da, algo="merge"), want)
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="rowtable"), want)
         assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T)
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True, algo="rowtable"), oracle.port().size_op(op, a, t).T)
         w = oracle.port().elem_op(op, t, a)
         assert_elems_equal(gpu_elems(op, dt, da), w)
         assert_elems_equal(gpu_elems(op, dt, da, algo="merge"), w)
+        assert_elems_equal(gpu_elems(op, dt, da, algo="rowtable"), w)
         off, ids, data = gpu_elems(op, dt, da, swap=True)
         w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
         assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
@@ -413,3 +416,25 @@ def test_rowwise_needs_equal_lengths():
         a.rowwise_size("ands", b)
     with pytest.raises(ValueError):
         a.andi(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_mask_table_kernel_many_tiles_and_groups(name):
+    """The 64-row mask-table kernel over several tiles of A (partial last tile), several 64-row
+    groups of B (partial last group) and rows of several 64-element chunks."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(99 + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, 150, 16384, 328, tu))
+    a = Batch(*util.ragged_rows(rng, 333, 16384, 328, au))
+    dt, da = dev(t, 16384), dev(a, 16384)
+    for op in range(4):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(gpu_sizes(op, dt, da), want), op
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), op
+    # ande through the mask-table fill (slots claimed concurrently, then sorted per pair)
+    assert_elems_equal(gpu_elems(AND, dt, da), oracle.port().elem_op(AND, t, a))
+    off, ids, data = gpu_elems(AND, dt, da, swap=True)
+    w_off, w_ids, w_data = oracle.port().elem_op(AND, a, t)
+    assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
+                          util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)

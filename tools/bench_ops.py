@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cases", default="c3,c4")
+    ap.add_argument("--only", default="", help="comma-separated size-op names to run (default: all four)")
     args = ap.parse_args()
     cases = []
     if "c3" in args.cases:
@@ -44,14 +45,23 @@ def main():
             cases.append(("c3", nq, args.rows, 2048, 40, False))
     if "c4" in args.cases:
         cases.append(("c4", 64, args.rows // 8, 16384, 328, True))
+    only = set(args.only.split(",")) if args.only else None
     for tag, nq, nd, width, active, unit in cases:
         q = SDRBatch.from_csr(*sdr_amd.synth_csr(2, 0, nq, width, active, unit), width=width)
         d = SDRBatch.from_csr(*sdr_amd.synth_csr(1, 0, nd, width, active, unit), width=width)
         eb = 8 if unit else 4
         in_bytes = nd * (eb * active + 4) + nq * (eb * active + 4)
         for sname, ename in (("ands", "ande"), ("ors", "ore"), ("xors", "xore"), ("rms", "rme")):
+            if only and sname not in only:
+                continue
             ms_s, counts = timed(lambda: getattr(q, sname)(d), args.reps)
-            ms_e, res = timed(lambda: getattr(q, ename)(d), args.reps)
+            try:
+                ms_e, res = timed(lambda: getattr(q, ename)(d), args.reps)
+            except sdr_amd.SdrbError as e:      # e.g. a union too large for 32-bit offsets: size op only
+                print(json.dumps({"case": tag, "queries": nq, "rows": nd, "size_op": sname, "size_ms": round(ms_s, 4),
+                                  "size_GBps": round((in_bytes + nq * nd * 4) / ms_s / 1e6, 1),
+                                  "elem_op": ename, "skipped": str(e)[:80]}), flush=True)
+                continue
             out_bytes = nq * nd * 4 + res.total * eb
             print(json.dumps({
                 "case": tag, "queries": nq, "rows": nd, "width": width, "active": active, "unit": unit,
