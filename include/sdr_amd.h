@@ -173,6 +173,26 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
                void* stream);
 
 /*
+ * Range and point queries for every row of a batch; `lo`, `hi`, `ids` are HOST arrays, outputs are
+ * device memory indexed [query][row] (ld_out >= rows of b).
+ *   sdrb_range_size:        out[r*ld_out + j] = B_j.ands(lo[r], hi[r])  (SDR.hpp:931-956): ids in [lo, hi)
+ *   sdrb_range_elems_count/_fill: B_j.ande(lo[r], hi[r])  (SDR.hpp:881-929) as CSR over the pairs (r, j),
+ *                            the same two-call protocol as the element ops; out_data may be NULL
+ *   sdrb_point_query:       out[q*ld_out + j] = position of ids[q] in row j, or -1 -- the batched
+ *                            ande(id) (SDR.hpp:860-879): present or not, and where its payload is
+ *                            (data[row_offsets[j] + position])
+ * A range with lo > hi violates the reference's precondition (SDR.hpp:884) and is refused.
+ */
+int sdrb_range_size(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
+                    uint32_t* out, uint64_t ld_out, void* stream);
+int sdrb_range_elems_count(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
+                           uint32_t* out_offsets, uint64_t* total, void* stream);
+int sdrb_range_elems_fill(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
+                          const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream);
+int sdrb_point_query(const sdrb_batch* b, uint64_t n_ids, const int32_t* ids, int32_t* out, uint64_t ld_out,
+                     void* stream);
+
+/*
  * All-pairs overlap with a fused per-row top-k.  For every row i of `a`, the k rows j of `b`
  * with the largest id overlap |a_i and b_j| -- the value `ands` returns for EmptyData elements
  * (SDR.hpp:1083-1095; payloads of UnitData batches are ignored here) -- ordered by overlap

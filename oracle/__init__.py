@@ -93,6 +93,52 @@ class _Impl:
         getattr(self.lib, self.prefix + "batch_size_op")(op, *t.args(), *a.args(), out.ctypes.data_as(_vp))
         return out
 
+    def range_size(self, b: Batch, lo, hi):
+        """(counts uint32 [n_ranges, b.n], firsts uint32 [n_ranges, b.n]) -- restatement only."""
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        fn = self.lib.osdr_batch_range_size
+        fn.restype, fn.argtypes = None, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]
+        counts = np.zeros((lo.size, b.n), dtype=np.uint32)
+        firsts = np.zeros((lo.size, b.n), dtype=np.uint32)
+        fn(b.off.ctypes.data_as(_vp), b.ids.ctypes.data_as(_vp), b.n, lo.size, lo.ctypes.data_as(_vp),
+           hi.ctypes.data_as(_vp), counts.ctypes.data_as(_vp), firsts.ctypes.data_as(_vp))
+        return counts, firsts
+
+    def point(self, b: Batch, qid):
+        """int32 [n_ids, b.n]: position of the id in the row or -1 -- restatement only."""
+        qid = np.ascontiguousarray(qid, dtype=np.int32)
+        fn = self.lib.osdr_batch_point
+        fn.restype, fn.argtypes = None, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]
+        pos = np.zeros((qid.size, b.n), dtype=np.int32)
+        fn(b.off.ctypes.data_as(_vp), b.ids.ctypes.data_as(_vp), b.n, qid.size, qid.ctypes.data_as(_vp),
+           pos.ctypes.data_as(_vp))
+        return pos
+
+    def ref_range(self, b: Batch, lo, hi):
+        """(counts, digests) from the reference's ands(lo, hi) / ande(lo, hi) -- reference build only."""
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        fn = self.lib.rsdr_batch_range
+        fn.restype = None
+        fn.argtypes = [_vp, _vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]
+        counts = np.zeros((lo.size, b.n), dtype=np.uint32)
+        digests = np.zeros((lo.size, b.n), dtype=np.int64)
+        fn(*b.args(), lo.size, lo.ctypes.data_as(_vp), hi.ctypes.data_as(_vp), counts.ctypes.data_as(_vp),
+           digests.ctypes.data_as(_vp))
+        return counts, digests
+
+    def ref_point(self, b: Batch, qid):
+        """(found uint8, value float32) from the reference's ande(id) -- reference build only."""
+        qid = np.ascontiguousarray(qid, dtype=np.int32)
+        fn = self.lib.rsdr_batch_point
+        fn.restype = None
+        fn.argtypes = [_vp, _vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, _vp]
+        found = np.zeros((qid.size, b.n), dtype=np.uint8)
+        value = np.zeros((qid.size, b.n), dtype=np.float32)
+        fn(*b.args(), qid.size, qid.ctypes.data_as(_vp), found.ctypes.data_as(_vp), value.ctypes.data_as(_vp))
+        return found, value
+
     def inner(self, t: Batch, a: Batch) -> np.ndarray:
         """float32 [t.n, a.n]: this_i.inner(arg_j) with ArithData<float> payloads on ``t`` and
         ArithData<float> (``a.data`` given) or EmptyData (``a.data`` None) on ``a``."""

@@ -195,6 +195,45 @@ uint64_t rsdr_batch_elem_op(int op, int inplace,
 }
 
 /* a.op(a) with the SAME object on both sides (src/test.cpp:241-272). Returns new length. */
+/* Range and point queries by the reference's own members: ands(lo, hi) (SDR.hpp:931-956), the ids of
+ * ande(lo, hi) (SDR.hpp:881-929; digest = sum of (k+1)*id over the slice, enough to pin content and order
+ * next to the count) and ande(id) (SDR.hpp:860-879; found flag and, for UnitData, the payload found). */
+void rsdr_batch_range(const uint64_t* off, const int32_t* ids, const float* data, int kind, uint64_t n,
+                      uint64_t n_ranges, const int32_t* lo, const int32_t* hi, uint32_t* counts, int64_t* digests) {
+    auto run = [&](auto rows) {
+        for (uint64_t r = 0; r < n_ranges; ++r)
+            for (uint64_t j = 0; j < n; ++j) {
+                counts[r * n + j] = (uint32_t)rows[j].ands(lo[r], hi[r]);
+                auto slice = rows[j].ande(lo[r], hi[r]);
+                int64_t d = 0, k = 0;
+                for (auto it = slice.cbegin(); it != slice.cend(); ++it) d += (++k) * (int64_t)it->id();
+                digests[r * n + j] = d + (int64_t)slice.size() * 1000003;
+            }
+    };
+    if (kind == K_UNIT) run(build<UnitSDR>(off, ids, data, n));
+    else run(build<EmptySDR>(off, ids, data, n));
+}
+
+void rsdr_batch_point(const uint64_t* off, const int32_t* ids, const float* data, int kind, uint64_t n,
+                      uint64_t n_ids, const int32_t* qid, uint8_t* found, float* value) {
+    if (kind == K_UNIT) {
+        auto rows = build<UnitSDR>(off, ids, data, n);
+        for (uint64_t q = 0; q < n_ids; ++q)
+            for (uint64_t j = 0; j < n; ++j) {
+                const UnitData* p = rows[j].ande(qid[q]);
+                found[q * n + j] = p != nullptr;
+                value[q * n + j] = p ? p->value() : -1.0f;
+            }
+    } else {
+        auto rows = build<EmptySDR>(off, ids, data, n);
+        for (uint64_t q = 0; q < n_ids; ++q)
+            for (uint64_t j = 0; j < n; ++j) {
+                found[q * n + j] = rows[j].ande(qid[q]) != nullptr;
+                value[q * n + j] = -1.0f;
+            }
+    }
+}
+
 /* this_i.inner(arg_j) on SDR<SDRElem<int, ArithData<float>>> rows (SDR.hpp:1682-1692); a_data == NULL:
  * the argument rows are SDR<SDRElem<int, EmptyData>>.  Also checks that diff_mul on the same rows,
  * taken as a row-major and a column-major matrix, produces the same entries (SDR.hpp:1886-1923). */

@@ -359,6 +359,41 @@ static osdr_view row_view(const uint64_t* off, const int32_t* ids, const float* 
     return v;
 }
 
+/* ---- range and point queries (SDR.hpp:860-956) ------------------------------------------ */
+static size_t lower_bound_id(const int32_t* ids, size_t n, int32_t key) {   /* std::lower_bound */
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        if (ids[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+void osdr_batch_range_size(const uint64_t* off, const int32_t* ids, uint64_t n, uint64_t n_ranges,
+                           const int32_t* lo, const int32_t* hi, uint32_t* counts, uint32_t* firsts) {
+    for (uint64_t r = 0; r < n_ranges; ++r)
+        for (uint64_t j = 0; j < n; ++j) {
+            const int32_t* row = ids + off[j];
+            size_t len = (size_t)(off[j + 1] - off[j]);
+            size_t pos = lower_bound_id(row, len, lo[r]);                       /* SDR.hpp:945 */
+            size_t end = pos + lower_bound_id(row + pos, len - pos, hi[r]);     /* SDR.hpp:946 */
+            counts[r * n + j] = (uint32_t)(end - pos);
+            if (firsts) firsts[r * n + j] = (uint32_t)pos;
+        }
+}
+
+void osdr_batch_point(const uint64_t* off, const int32_t* ids, uint64_t n, uint64_t n_ids,
+                      const int32_t* qid, int32_t* position) {
+    for (uint64_t q = 0; q < n_ids; ++q)
+        for (uint64_t j = 0; j < n; ++j) {
+            const int32_t* row = ids + off[j];
+            size_t len = (size_t)(off[j + 1] - off[j]);
+            size_t pos = lower_bound_id(row, len, qid[q]);                      /* SDR.hpp:866 */
+            position[q * n + j] = (pos == len || row[pos] != qid[q]) ? -1 : (int32_t)pos;   /* SDR.hpp:868-872 */
+        }
+}
+
 /* ---- inner (SDR.hpp:1682-1692) ---------------------------------------------------------- */
 typedef struct {
     const float* t_data;

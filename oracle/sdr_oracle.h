@@ -69,6 +69,17 @@ size_t osdr_inplace_op(int op, int32_t* t_ids, float* t_data, size_t t_n, int t_
                        const osdr_view* a);
 
 /* Host loops over CSR batches: out[i*a_n + j] = this_i.op(arg_j). */
+/* Range and point queries on every row of a batch.
+ *   counts[r * n + j]   = row_j.ands(lo[r], hi[r])   (SDR.hpp:931-956): two lower_bounds, the second
+ *                         starting at the first one's result
+ *   position[q * n + j] = index of qid[q] in row j or -1: what ande(id) finds (SDR.hpp:860-879:
+ *                         lower_bound, then the id must be equal)
+ * The slices of ande(lo, hi) (SDR.hpp:881-929) are rows[j][first .. first + count). */
+void osdr_batch_range_size(const uint64_t* off, const int32_t* ids, uint64_t n, uint64_t n_ranges,
+                           const int32_t* lo, const int32_t* hi, uint32_t* counts, uint32_t* firsts);
+void osdr_batch_point(const uint64_t* off, const int32_t* ids, uint64_t n, uint64_t n_ids,
+                      const int32_t* qid, int32_t* position);
+
 /* SDR::inner on ArithData<float> elements (SDR.hpp:1682-1692): for every id match, in ascending
  * id order, acc += this_value * arg_value -- a rounded product (ArithData.hpp:37-43, value_ *=)
  * followed by a rounded sum (ArithData.hpp:59-63, value_ +=), starting from ArithData() = 0

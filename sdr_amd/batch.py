@@ -241,6 +241,47 @@ class SDRBatch:
                                      _stream_handle(other.device, stream)))
         return out
 
+    # -- range and point queries -----------------------------------------------------------------
+    def range_size(self, lo, hi, *, stream=None):
+        """``out[r, j] = self[j].ands(lo[r], hi[r])``: ids of row j in ``[lo, hi)`` (SDR.hpp:931-956)."""
+        torch = _torch()
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        out = torch.empty((max(lo.size, 1), max(self.n_rows, 1)), dtype=torch.int32, device=f"cuda:{self.device}")
+        check(self._lib.sdrb_range_size(self._h, lo.size, lo.ctypes.data, hi.ctypes.data, out.data_ptr(),
+                                        out.stride(0), _stream_handle(self.device, stream)))
+        return out[: lo.size, : self.n_rows]
+
+    def range_elems(self, lo, hi, *, stream=None) -> ElemResult:
+        """CSR of ``self[j].ande(lo[r], hi[r])`` over the pairs (r, j) (SDR.hpp:881-929)."""
+        torch = _torch()
+        dev = f"cuda:{self.device}"
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        s = _stream_handle(self.device, stream)
+        pairs = lo.size * self.n_rows
+        offsets = torch.empty(pairs + 1, dtype=torch.int32, device=dev)
+        total = C.c_uint64()
+        check(self._lib.sdrb_range_elems_count(self._h, lo.size, lo.ctypes.data, hi.ctypes.data, offsets.data_ptr(),
+                                               C.byref(total), s))
+        n = int(total.value)
+        ids_buf = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if self.data_kind != DATA_EMPTY else None
+        check(self._lib.sdrb_range_elems_fill(self._h, lo.size, lo.ctypes.data, hi.ctypes.data, offsets.data_ptr(),
+                                              ids_buf.data_ptr(),
+                                              data_buf.data_ptr() if data_buf is not None else None, s))
+        return ElemResult(lo.size, self.n_rows, offsets, ids_buf[:n], data_buf[:n] if data_buf is not None else None, n)
+
+    def point_query(self, ids, *, stream=None):
+        """``out[q, j]`` = position of ``ids[q]`` in row j or -1: the batched ``ande(id)``
+        (SDR.hpp:860-879); the payload of a hit is ``data[row_offsets[j] + position]``."""
+        torch = _torch()
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        out = torch.empty((max(ids.size, 1), max(self.n_rows, 1)), dtype=torch.int32, device=f"cuda:{self.device}")
+        check(self._lib.sdrb_point_query(self._h, ids.size, ids.ctypes.data, out.data_ptr(), out.stride(0),
+                                         _stream_handle(self.device, stream)))
+        return out[: ids.size, : self.n_rows]
+
     def inner(self, other: "SDRBatch", *, out=None, stream=None):
         """``out[i, j] = self[i].inner(other[j])`` (float32): the sparse dot product over the id
         matches in ascending id order, product and sum rounded separately, bit-exact against the

@@ -552,6 +552,101 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
 }
 
+namespace {
+int check_queries(const sdrb_batch* b, uint64_t n, const int32_t* lo, const int32_t* hi, bool ranges) {
+    if (!b || !b->d_offsets) {
+        sdrb::set_error("null batch handle or no uploaded rows");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (n && (!lo || (ranges && !hi))) {
+        sdrb::set_error("query arrays are null");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (n > 0xFFFFFFFFull) {
+        sdrb::set_error("too many queries for one call");
+        return SDRB_ERR_OVERFLOW;
+    }
+    if (ranges)
+        for (uint64_t r = 0; r < n; ++r)
+            if (lo[r] > hi[r]) {
+                sdrb::set_error("range %llu has start %d > stop %d", (unsigned long long)r, lo[r], hi[r]);
+                return SDRB_ERR_INVALID_ARG;
+            }
+    return SDRB_OK;
+}
+}  // namespace
+
+int sdrb_range_size(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
+                    uint32_t* out, uint64_t ld_out, void* stream) {
+    int rc = check_queries(b, n_ranges, lo, hi, true);
+    if (rc != SDRB_OK) return rc;
+    if (n_ranges == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || ld_out < b->n_rows) {
+        set_error("sdrb_range_size: out is null or ld_out < rows of b");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    return launch_range_query(b, 0, n_ranges, lo, hi, out, ld_out, nullptr, nullptr, nullptr,
+                              static_cast<hipStream_t>(stream));
+}
+
+int sdrb_range_elems_count(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
+                           uint32_t* out_offsets, uint64_t* total, void* stream) {
+    int rc = check_queries(b, n_ranges, lo, hi, true);
+    if (rc != SDRB_OK) return rc;
+    if (!out_offsets || !total) {
+        set_error("sdrb_range_elems_count: null output");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const uint64_t pairs = n_ranges * b->n_rows;
+    if (pairs >= 0xFFFFFFFFull || n_ranges * b->nnz > 0xFFFFFFFFull) {
+        set_error("result may exceed 2^32-1 pairs or elements; use fewer ranges per call");
+        return SDRB_ERR_OVERFLOW;
+    }
+    DeviceGuard guard(b->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pairs) {
+        rc = launch_range_query(b, 0, n_ranges, lo, hi, out_offsets, b->n_rows, nullptr, nullptr, nullptr, s);
+        if (rc != SDRB_OK) return rc;
+    }
+    SDRB_HIP(hipMemsetAsync(out_offsets + pairs, 0, sizeof(uint32_t), s));
+    rc = launch_exclusive_scan_u32(b->device, out_offsets, pairs + 1, s);
+    if (rc != SDRB_OK) return rc;
+    uint32_t t32 = 0;
+    SDRB_HIP(hipMemcpyAsync(&t32, out_offsets + pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    *total = t32;
+    return SDRB_OK;
+}
+
+int sdrb_range_elems_fill(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
+                          const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
+    int rc = check_queries(b, n_ranges, lo, hi, true);
+    if (rc != SDRB_OK) return rc;
+    if (n_ranges == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out_offsets || !out_ids) {
+        set_error("sdrb_range_elems_fill: null output");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    return launch_range_query(b, 1, n_ranges, lo, hi, nullptr, 0, out_offsets, out_ids,
+                              has_payload(b) ? out_data : nullptr, static_cast<hipStream_t>(stream));
+}
+
+int sdrb_point_query(const sdrb_batch* b, uint64_t n_ids, const int32_t* ids, int32_t* out, uint64_t ld_out,
+                     void* stream) {
+    int rc = check_queries(b, n_ids, ids, nullptr, false);
+    if (rc != SDRB_OK) return rc;
+    if (n_ids == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || ld_out < b->n_rows) {
+        set_error("sdrb_point_query: out is null or ld_out < rows of b");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    return launch_range_query(b, 2, n_ids, ids, nullptr, reinterpret_cast<uint32_t*>(out), ld_out, nullptr, nullptr,
+                              nullptr, static_cast<hipStream_t>(stream));
+}
+
 int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
                void* stream) {
     (void)flags;

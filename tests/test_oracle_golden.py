@@ -129,6 +129,17 @@ def test_inner_golden(golden, tag):
     assert not np.array_equal(approx.view(np.uint32), g["small_aa_bits"])
 
 
+@pytest.mark.parametrize("tag", ["e", "u"])
+def test_queries_golden(golden, tag):
+    """Range / point queries (SDR.hpp:860-956): the restatement against the reference's fixture."""
+    g = golden("queries.npz")
+    b = oracle.Batch(g[f"{tag}_off"], g[f"{tag}_ids"], g[f"{tag}_data"] if tag == "u" else None)
+    counts, firsts = oracle.port().range_size(b, g[f"{tag}_lo"], g[f"{tag}_hi"])
+    assert np.array_equal(counts, g[f"{tag}_counts"])
+    pos = oracle.port().point(b, g[f"{tag}_qid"])
+    assert np.array_equal(pos >= 0, g[f"{tag}_found"].astype(bool))
+
+
 def test_readme_known_answers():
     # README.md:65-70
     assert _one(AND, [1, 2], [2, 3])[0] == [2]

@@ -178,14 +178,56 @@ def gen_inner():
     np.savez_compressed(os.path.join(OUT, "inner.npz"), **out)
 
 
+def gen_queries():
+    """Range and point queries (SDR.hpp:860-956): the reference's ands(lo,hi) / ande(lo,hi) / ande(id) on
+    ragged rows with signed ids; the restatement must give the same counts, slices and hits."""
+    rng = np.random.default_rng(FUZZ_SEED + 11)
+    out = {}
+    for tag, with_data in (("e", False), ("u", True)):
+        b = oracle.Batch(*util.ragged_rows(rng, 300, 400, 60, with_data, lo=-150))
+        lo = rng.integers(-170, 270, 40).astype(np.int32)
+        hi = (lo + rng.integers(0, 200, 40)).astype(np.int32)
+        lo[:3], hi[:3] = [-1000, 0, 249], [1000, 0, 250]          # everything, an empty range, one id
+        qid = rng.integers(-160, 260, 50).astype(np.int32)
+        ref_counts, ref_digests = oracle.reference(debug=True).ref_range(b, lo, hi)
+        counts, firsts = oracle.port().range_size(b, lo, hi)
+        assert np.array_equal(ref_counts, counts)
+        # the slices the restatement implies reproduce the reference's ande(lo, hi)
+        dig = np.zeros_like(ref_digests)
+        for r in range(lo.size):
+            for j in range(b.n):
+                ids, _ = b.row(j)
+                sl = ids[firsts[r, j]: firsts[r, j] + counts[r, j]].astype(np.int64)
+                dig[r, j] = int((np.arange(1, sl.size + 1) * sl).sum()) + sl.size * 1000003
+        assert np.array_equal(dig, ref_digests)
+        found, value = oracle.reference(debug=True).ref_point(b, qid)
+        pos = oracle.port().point(b, qid)
+        assert np.array_equal(found.astype(bool), pos >= 0)
+        if with_data:
+            for q in range(qid.size):
+                for j in range(b.n):
+                    if pos[q, j] >= 0:
+                        assert b.row(j)[1][pos[q, j]] == value[q, j]
+        out.update({f"{tag}_off": b.off, f"{tag}_ids": b.ids, f"{tag}_lo": lo, f"{tag}_hi": hi, f"{tag}_qid": qid,
+                    f"{tag}_counts": ref_counts, f"{tag}_digests": ref_digests, f"{tag}_found": found,
+                    f"{tag}_value": value})
+        if with_data:
+            out[f"{tag}_data"] = b.data
+    np.savez_compressed(os.path.join(OUT, "queries.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not oracle.have_reference():
         sys.exit("oracle/_ref is not built: this script needs /root/reference (make -C oracle)")
+    if sys.argv[1:] == ["queries"]:     # only the fixture of the range / point queries
+        gen_queries()
+        return
     if sys.argv[1:] == ["inner"]:       # only the fixture of the sparse dot products
         gen_inner()
         return
     gen_inner()
+    gen_queries()
     gen_fuzz_sizes()
     gen_fuzz_elems()
     gen_mini("mini_2048_40.npz", 8, 4096, 2048, 40, False)
