@@ -173,6 +173,16 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
                void* stream);
 
 /*
+ * Transpose of a batch seen as a sparse matrix (rows x ids): `dst` gets one row per id c in
+ * [0, width of src), listing the rows of `src` that contain c in ascending order, each with the
+ * payload it had there; dst's declared width becomes the row count of src.  This is SDR::transpose
+ * (SDR.hpp:1807-1826, MatrixUtils.hpp:13-190) for a matrix stored as the rows of a batch -- CSR to
+ * CSC -- e.g. to build the inverted index of a database.  `src` needs a declared width, `dst` the
+ * same payload kind and device; `dst` may not be `src`.
+ */
+int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream);
+
+/*
  * Range and point queries for every row of a batch; `lo`, `hi`, `ids` are HOST arrays, outputs are
  * device memory indexed [query][row] (ld_out >= rows of b).
  *   sdrb_range_size:        out[r*ld_out + j] = B_j.ands(lo[r], hi[r])  (SDR.hpp:931-956): ids in [lo, hi)

@@ -139,6 +139,18 @@ class _Impl:
         fn(*b.args(), qid.size, qid.ctypes.data_as(_vp), found.ctypes.data_as(_vp), value.ctypes.data_as(_vp))
         return found, value
 
+    def ref_transpose(self, b: Batch, width: int):
+        """(col_off uint64 [width+1], rows int32, vals float32) from the reference's transpose(), in the
+        order the reference emitted the elements -- reference build only."""
+        fn = self.lib.rsdr_transpose
+        fn.restype, fn.argtypes = None, [_vp, _vp, _vp, C.c_uint64, C.c_int32, _vp, _vp, _vp]
+        col_off = np.zeros(width + 1, dtype=np.uint64)
+        rows = np.zeros(b.ids.size, dtype=np.int32)
+        vals = np.zeros(b.ids.size, dtype=np.float32)
+        fn(b.off.ctypes.data_as(_vp), b.ids.ctypes.data_as(_vp), b.data.ctypes.data_as(_vp), b.n, width,
+           col_off.ctypes.data_as(_vp), rows.ctypes.data_as(_vp), vals.ctypes.data_as(_vp))
+        return col_off, rows, vals
+
     def inner(self, t: Batch, a: Batch) -> np.ndarray:
         """float32 [t.n, a.n]: this_i.inner(arg_j) with ArithData<float> payloads on ``t`` and
         ArithData<float> (``a.data`` given) or EmptyData (``a.data`` None) on ``a``."""

@@ -195,6 +195,33 @@ uint64_t rsdr_batch_elem_op(int op, int inplace,
 }
 
 /* a.op(a) with the SAME object on both sides (src/test.cpp:241-272). Returns new length. */
+/* SDR::transpose (SDR.hpp:1807-1826) of the matrix whose rows are the given batch rows (row id = row
+ * number, ArithData<float> payloads; empty rows are left out, MatrixUtils.hpp:59-61).  Writes the
+ * result column by column, in the order the reference produced it: col_off[width + 1], rows[], vals[]. */
+void rsdr_transpose(const uint64_t* off, const int32_t* ids, const float* data, uint64_t n, int32_t width,
+                    uint64_t* col_off, int32_t* rows, float* vals) {
+    using Elem = SDRElem<int, ArithData<float>>;
+    using Row = SDRElem<int, SDR<Elem>>;
+    SDR<Row> m;
+    for (uint64_t r = 0; r < n; ++r) {
+        if (off[r] == off[r + 1]) continue;
+        SDR<Elem> row;
+        for (uint64_t k = off[r]; k < off[r + 1]; ++k) row.push_back(Elem(ids[k], ArithData<float>(data[k])));
+        m.push_back(Row((int)r, std::move(row)));
+    }
+    auto t = m.transpose();
+    uint64_t w = 0;
+    int32_t next_col = 0;
+    for (auto it = t.cbegin(); it != t.cend(); ++it) {
+        for (; next_col <= it->id(); ++next_col) col_off[next_col] = w;
+        for (auto e = it->data().cbegin(); e != it->data().cend(); ++e, ++w) {
+            rows[w] = e->id();
+            vals[w] = e->data().value();
+        }
+    }
+    for (; next_col <= width; ++next_col) col_off[next_col] = w;
+}
+
 /* Range and point queries by the reference's own members: ands(lo, hi) (SDR.hpp:931-956), the ids of
  * ande(lo, hi) (SDR.hpp:881-929; digest = sum of (k+1)*id over the slice, enough to pin content and order
  * next to the count) and ande(id) (SDR.hpp:860-879; found flag and, for UnitData, the payload found). */

@@ -241,6 +241,16 @@ class SDRBatch:
                                      _stream_handle(other.device, stream)))
         return out
 
+    def transpose(self, *, stream=None) -> "SDRBatch":
+        """The batch regrouped by id (CSR -> CSC): row c of the result lists the rows of ``self`` that
+        contain id c, ascending, with their payloads -- ``SDR::transpose`` (SDR.hpp:1807-1826) for a
+        matrix stored as the rows of a batch.  Needs a declared width."""
+        t = SDRBatch(self.device, 0, self.data_kind)
+        check(self._lib.sdrb_batch_transpose(self._h, t._h, _stream_handle(self.device, stream)))
+        t._refresh_info()
+        t.width = self.n_rows
+        return t
+
     # -- range and point queries -----------------------------------------------------------------
     def range_size(self, lo, hi, *, stream=None):
         """``out[r, j] = self[j].ands(lo[r], hi[r])``: ids of row j in ``[lo, hi)`` (SDR.hpp:931-956)."""

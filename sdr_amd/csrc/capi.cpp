@@ -552,6 +552,41 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
 }
 
+int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
+    if (!src || !dst || src == dst || !src->d_offsets) {
+        set_error("sdrb_batch_transpose: null, identical or empty handles");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (src->width <= 0 || src->device != dst->device || src->data_kind != dst->data_kind) {
+        set_error("sdrb_batch_transpose: src needs a declared width; dst the same device and payload kind");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (src->n_rows > 0x7FFFFFFFull) {
+        set_error("too many rows to become ids");
+        return SDRB_ERR_OVERFLOW;
+    }
+    DeviceGuard guard(src->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t width = (uint64_t)src->width;
+    int rc = reserve_batch_storage(dst, width, src->nnz);
+    if (rc != SDRB_OK) return rc;
+    rc = launch_transpose(src, dst->d_offsets, dst->d_ids, dst->d_data, s);
+    if (rc != SDRB_OK) return rc;
+    // the longest column, from the column offsets (width + 1 integers)
+    std::vector<uint32_t> off(width + 1);
+    SDRB_HIP(hipMemcpyAsync(off.data(), dst->d_offsets, (width + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    uint32_t longest = 0;
+    for (uint64_t c = 0; c < width; ++c) longest = std::max(longest, off[c + 1] - off[c]);
+    dst->n_rows = width;
+    dst->nnz = src->nnz;
+    dst->max_row_len = longest;
+    dst->width = (int32_t)src->n_rows;
+    dst->min_id = 0;                                   // bounds of the row numbers (not necessarily attained)
+    dst->max_id = src->nnz ? (int32_t)src->n_rows - 1 : -1;
+    return SDRB_OK;
+}
+
 namespace {
 int check_queries(const sdrb_batch* b, uint64_t n, const int32_t* lo, const int32_t* hi, bool ranges) {
     if (!b || !b->d_offsets) {

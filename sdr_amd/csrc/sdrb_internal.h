@@ -37,7 +37,8 @@ void set_error(const char* fmt, ...);
 // Per-device scratch that grows on demand and lives until process exit.
 // slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
 // slot 4: partial top-k lists; slot 5: interleaved value table of A (dot products);
-// slot 6: dense payload matrix of A (mask-table kernel); slot 7: staged range / point queries.
+// slot 6: dense payload matrix of A (mask-table kernel); slot 7: staged range / point queries;
+// slot 8: sort buffers of the transpose.
 void* workspace(int device, int slot, size_t bytes);
 
 #define SDRB_HIP(call)                                                                   \
@@ -120,6 +121,10 @@ int launch_elem_mask_table(const sdrb_batch* a, const sdrb_batch* b, bool swap, 
 int launch_range_query(const sdrb_batch* b, int mode, uint64_t n_queries, const int32_t* lo, const int32_t* hi,
                        uint32_t* out, uint64_t ld_out, const uint32_t* out_off, int32_t* out_ids, float* out_data,
                        hipStream_t stream);
+
+// transpose.hip ---------------------------------------------------------------------------
+// dst_off[width + 1], dst_ids[nnz] (row numbers of src), dst_data[nnz]: the batch regrouped by id.
+int launch_transpose(const sdrb_batch* src, uint32_t* dst_off, int32_t* dst_ids, float* dst_data, hipStream_t stream);
 
 // inner.hip --------------------------------------------------------------------------------
 // Sparse dot products of ArithData<float> rows for every pair (SDR::inner, SDR.hpp:1682-1692).

@@ -65,3 +65,53 @@ def test_queries_vs_oracle_large_and_rejections():
     with pytest.raises(SdrbError):
         b.range_size([5], [4])            # start > stop: the reference's precondition (SDR.hpp:884)
     assert b.range_size([], []).shape == (0, 5000)
+
+
+def _wire(b):
+    w = b.to_wire().cpu().numpy()
+    off = w[: b.n_rows + 1].view(np.uint32).astype(np.uint64)
+    ids = w[b.n_rows + 1: b.n_rows + 1 + b.nnz]
+    data = w[b.n_rows + 1 + b.nnz:].view(np.float32) if w.size > b.n_rows + 1 + b.nnz else None
+    return off, ids, data
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_transpose_vs_reference_columns(golden, tag):
+    """CSR -> CSC against the reference's transpose(): the same elements in every column; within a
+    column ascending by row (the reference itself emits heap order there, so the fixture holds its
+    columns sorted by row -- the order of its own 2x2 known answers)."""
+    from sdr_amd import SDRBatch
+    g = golden("transpose.npz")
+    width = int(g[f"{tag}_width"])
+    b = SDRBatch.from_csr(g[f"{tag}_off"], g[f"{tag}_ids"], g[f"{tag}_data"], width=width, kind="arith")
+    t = b.transpose()
+    assert (t.n_rows, t.nnz, t.width) == (width, b.nnz, b.n_rows)
+    off, rows, vals = _wire(t)
+    assert np.array_equal(off, g[f"{tag}_col_off"])
+    assert np.array_equal(rows, g[f"{tag}_rows"])
+    assert np.array_equal(vals.view(np.uint32), g[f"{tag}_vals"].view(np.uint32))
+    # transposing back restores the batch (every row of the source is non-empty or simply absent)
+    back = t.transpose()
+    b_off, b_ids, b_vals = _wire(back)
+    assert np.array_equal(b_off, g[f"{tag}_off"]) and np.array_equal(b_ids, g[f"{tag}_ids"])
+    assert np.array_equal(b_vals.view(np.uint32), g[f"{tag}_data"].view(np.uint32))
+
+
+def test_transpose_known_answer_and_inverted_index():
+    """The reference's 2x2 case (src/test.cpp:517-527): [[1 2] [3 4]] -> [[1 3] [2 4]]; and an id-only
+    database's transpose is its inverted index: row c = the rows containing id c."""
+    from sdr_amd import SDRBatch
+    m = SDRBatch.from_csr(np.array([0, 2, 4], np.uint64), np.array([0, 1, 0, 1], np.int32),
+                          np.array([1, 2, 3, 4], np.float32), width=2, kind="arith")
+    off, rows, vals = _wire(m.transpose())
+    assert off.tolist() == [0, 2, 4] and rows.tolist() == [0, 1, 0, 1] and vals.tolist() == [1, 3, 2, 4]
+    rng = np.random.default_rng(9)
+    d_off, d_ids, _ = util.ragged_rows(rng, 4000, 2048, 40, False)
+    inv = SDRBatch.from_csr(d_off, d_ids, None, width=2048).transpose()
+    off, rows, _ = _wire(inv)
+    for c in (0, 17, 2047):
+        want = [r for r in range(4000) if c in d_ids[int(d_off[r]):int(d_off[r + 1])]]
+        assert rows[int(off[c]):int(off[c + 1])].tolist() == want
+    # the inverted index answers a point query for all rows at once
+    hits = SDRBatch.from_csr(d_off, d_ids, None, width=2048).point_query([17]).cpu().numpy()[0] >= 0
+    assert np.flatnonzero(hits).tolist() == rows[int(off[17]):int(off[18])].tolist()

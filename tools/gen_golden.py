@@ -216,10 +216,33 @@ def gen_queries():
     np.savez_compressed(os.path.join(OUT, "queries.npz"), **out)
 
 
+def gen_transpose():
+    """SDR::transpose (SDR.hpp:1807-1826) on a matrix stored as batch rows.  The reference emits every
+    column's elements in the pop order of its priority queue (MatrixUtils.hpp:13-75), which for equal
+    column ids is heap order, not row order; the fixture holds the reference's columns with their
+    elements sorted by row (the order its own 2x2 known answers show, src/test.cpp:517-571)."""
+    rng = np.random.default_rng(FUZZ_SEED + 13)
+    out = {}
+    for tag, (n, width, max_len) in {"small": (300, 64, 30), "wide": (500, 5000, 60)}.items():
+        b = oracle.Batch(*util.arith_rows(rng, n, width, max_len))
+        col_off, rows, vals = oracle.reference(debug=False).ref_transpose(b, width)
+        assert int(col_off[-1]) == b.ids.size
+        for c in range(width):
+            lo, hi = int(col_off[c]), int(col_off[c + 1])
+            order = np.argsort(rows[lo:hi], kind="stable")
+            rows[lo:hi], vals[lo:hi] = rows[lo:hi][order], vals[lo:hi][order]
+        out.update({f"{tag}_off": b.off, f"{tag}_ids": b.ids, f"{tag}_data": b.data, f"{tag}_width": width,
+                    f"{tag}_col_off": col_off, f"{tag}_rows": rows, f"{tag}_vals": vals})
+    np.savez_compressed(os.path.join(OUT, "transpose.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not oracle.have_reference():
         sys.exit("oracle/_ref is not built: this script needs /root/reference (make -C oracle)")
+    if sys.argv[1:] == ["transpose"]:
+        gen_transpose()
+        return
     if sys.argv[1:] == ["queries"]:     # only the fixture of the range / point queries
         gen_queries()
         return
@@ -228,6 +251,7 @@ def main():
         return
     gen_inner()
     gen_queries()
+    gen_transpose()
     gen_fuzz_sizes()
     gen_fuzz_elems()
     gen_mini("mini_2048_40.npz", 8, 4096, 2048, 40, False)
