@@ -111,6 +111,16 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
                                  const int32_t* ids, const float* data, void* stream);
 
 /*
+ * Batches with 64-bit ids (the reference's SDRElem<long, ...>, fuzzed in src/fuzz.cpp:413-423).
+ * Such a batch has no declared width and EmptyData or UnitData payloads; it is taken by sdrb_size_op,
+ * sdrb_elem_op_count and sdrb_elem_op_fill64 (both batches of a call must hold ids of the same
+ * width; the per-pair merge kernels serve them), and refused by everything else.
+ */
+int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out);
+int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
+                            const int64_t* ids, const float* data, void* stream);
+
+/*
  * Makes the batch a VIEW of a CSR pack in this device's memory: nothing is copied, checked or
  * synchronised.  The caller vouches that the arrays hold a batch that has already been
  * validated (e.g. the arrays of another rank's uploaded batch, received over RCCL together with
@@ -236,6 +246,8 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
  */
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                        uint32_t* out_offsets, uint64_t* total, void* stream);
+int sdrb_elem_op_fill64(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                        const uint32_t* out_offsets, int64_t* out_ids, float* out_data, void* stream);
 int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                       const uint32_t* out_offsets, int32_t* out_ids, float* out_data,
                       void* stream);

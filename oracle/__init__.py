@@ -151,6 +151,36 @@ class _Impl:
            col_off.ctypes.data_as(_vp), rows.ctypes.data_as(_vp), vals.ctypes.data_as(_vp))
         return col_off, rows, vals
 
+    def ref_op64(self, op: int, elems: bool, t_csr, a_csr):
+        """The reference on rows with `long` ids: (off uint64, ids int64, data-or-None) per side.  Returns
+        sizes uint32 [nt, na], or (offsets, ids int64, data) of the element op -- reference build only."""
+        def args(csr):
+            off, ids, data = csr
+            off = np.ascontiguousarray(off, dtype=np.uint64)
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            data = None if data is None else np.ascontiguousarray(data, dtype=np.float32)
+            keep.extend([off, ids, data])
+            return [off.ctypes.data_as(_vp), ids.ctypes.data_as(_vp),
+                    data.ctypes.data_as(_vp) if data is not None else None, UNIT if data is not None else EMPTY,
+                    off.size - 1]
+        keep = []
+        fn = self.lib.rsdr_batch_op64
+        fn.restype = C.c_uint64
+        fn.argtypes = [C.c_int, C.c_int] + [_vp, _vp, _vp, C.c_int, C.c_uint64] * 2 + [_vp, _vp, _vp, _vp]
+        ta, aa = args(t_csr), args(a_csr)
+        nt, na = ta[4], aa[4]
+        if not elems:
+            sizes = np.zeros((nt, na), dtype=np.uint32)
+            fn(op, 0, *ta, *aa, sizes.ctypes.data_as(_vp), None, None, None)
+            return sizes
+        off = np.zeros(nt * na + 1, dtype=np.uint64)
+        total = fn(op, 1, *ta, *aa, None, off.ctypes.data_as(_vp), None, None)
+        ids = np.zeros(total, dtype=np.int64)
+        data = np.zeros(total, dtype=np.float32) if t_csr[2] is not None else None
+        fn(op, 1, *ta, *aa, None, off.ctypes.data_as(_vp), ids.ctypes.data_as(_vp),
+           data.ctypes.data_as(_vp) if data is not None else None)
+        return off, ids, data
+
     def inner(self, t: Batch, a: Batch) -> np.ndarray:
         """float32 [t.n, a.n]: this_i.inner(arg_j) with ArithData<float> payloads on ``t`` and
         ArithData<float> (``a.data`` given) or EmptyData (``a.data`` None) on ``a``."""

@@ -222,6 +222,67 @@ void rsdr_transpose(const uint64_t* off, const int32_t* ids, const float* data, 
     for (; next_col <= width; ++next_col) col_off[next_col] = w;
 }
 
+/* The size and element ops on rows with `long` ids, SDR<SDRElem<long, Data>> (the id type the reference's
+ * fuzzer also covers, src/fuzz.cpp:413-423). */
+}  // extern "C"  (templates need C++ linkage)
+namespace {
+template <typename Data>
+std::vector<SDR<SDRElem<long, Data>>> build_long(const uint64_t* off, const int64_t* ids, const float* data, uint64_t n) {
+    std::vector<SDR<SDRElem<long, Data>>> rows(n);
+    for (uint64_t r = 0; r < n; ++r)
+        for (uint64_t k = off[r]; k < off[r + 1]; ++k) {
+            if constexpr (std::is_same_v<Data, UnitData>) rows[r].push_back(SDRElem<long, Data>((long)ids[k], UnitData(data[k])));
+            else rows[r].push_back(SDRElem<long, Data>((long)ids[k]));
+        }
+    return rows;
+}
+
+template <typename A, typename B>
+uint64_t run_long(int op, bool elems, const std::vector<A>& t, const std::vector<B>& a, uint32_t* sizes,
+                  uint64_t* out_off, int64_t* out_ids, float* out_data) {
+    uint64_t total = 0;
+    for (size_t i = 0; i < t.size(); ++i)
+        for (size_t j = 0; j < a.size(); ++j) {
+            if (!elems) {
+                sizes[i * a.size() + j] = (uint32_t)size_op(op, t[i], a[j]);
+                continue;
+            }
+            out_off[i * a.size() + j] = total;
+            A r = elem_op(op, t[i], a[j]);
+            if (out_ids) {
+                uint64_t k = total;
+                for (auto it = r.cbegin(); it != r.cend(); ++it, ++k) {
+                    out_ids[k] = (int64_t)it->id();
+                    if constexpr (std::is_same_v<typename A::value_type::data_type, UnitData>) {
+                        if (out_data) out_data[k] = it->data().value();
+                    }
+                }
+            }
+            total += r.size();
+        }
+    if (elems) out_off[t.size() * a.size()] = total;
+    return total;
+}
+}  // namespace
+extern "C" {
+
+uint64_t rsdr_batch_op64(int op, int elems,
+                         const uint64_t* t_off, const int64_t* t_ids, const float* t_data, int t_kind, uint64_t t_n,
+                         const uint64_t* a_off, const int64_t* a_ids, const float* a_data, int a_kind, uint64_t a_n,
+                         uint32_t* sizes, uint64_t* out_off, int64_t* out_ids, float* out_data) {
+    if (t_kind == K_UNIT && a_kind == K_UNIT)
+        return run_long(op, elems != 0, build_long<UnitData>(t_off, t_ids, t_data, t_n),
+                        build_long<UnitData>(a_off, a_ids, a_data, a_n), sizes, out_off, out_ids, out_data);
+    if (t_kind == K_UNIT)
+        return run_long(op, elems != 0, build_long<UnitData>(t_off, t_ids, t_data, t_n),
+                        build_long<EmptyData>(a_off, a_ids, a_data, a_n), sizes, out_off, out_ids, out_data);
+    if (a_kind == K_UNIT)
+        return run_long(op, elems != 0, build_long<EmptyData>(t_off, t_ids, t_data, t_n),
+                        build_long<UnitData>(a_off, a_ids, a_data, a_n), sizes, out_off, out_ids, out_data);
+    return run_long(op, elems != 0, build_long<EmptyData>(t_off, t_ids, t_data, t_n),
+                    build_long<EmptyData>(a_off, a_ids, a_data, a_n), sizes, out_off, out_ids, out_data);
+}
+
 /* Range and point queries by the reference's own members: ands(lo, hi) (SDR.hpp:931-956), the ids of
  * ande(lo, hi) (SDR.hpp:881-929; digest = sum of (k+1)*id over the slice, enough to pin content and order
  * next to the count) and ande(id) (SDR.hpp:860-879; found flag and, for UnitData, the payload found). */

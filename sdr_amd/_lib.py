@@ -45,6 +45,9 @@ PROTOTYPES = {
     "sdrb_last_error": (C.c_char_p, []),
     "sdrb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sdrb_batch_create": (C.c_int, [C.c_int, C.c_int32, C.c_int, C.POINTER(_vp)]),
+    "sdrb_batch_create64": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "sdrb_batch_upload_csr64": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "sdrb_elem_op_fill64": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),
     "sdrb_batch_upload_csr": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "sdrb_batch_upload_device_csr": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "sdrb_batch_adopt_device_csr": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_int32]),

@@ -76,13 +76,21 @@ class ElemResult:
 class SDRBatch:
     """A device-resident CSR pack of SDRs (ids int32, optional UnitData float payloads)."""
 
-    def __init__(self, device: int = 0, width: int = 0, data_kind="empty"):
+    def __init__(self, device: int = 0, width: int = 0, data_kind="empty", id_bits: int = 32):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.device = int(device)
         self.width = int(width)
         self.data_kind = _KINDS[data_kind]
-        check(self._lib.sdrb_batch_create(self.device, self.width, self.data_kind, C.byref(self._h)))
+        self.id_bits = int(id_bits)
+        if self.id_bits == 64:      # the reference's SDRElem<long, ...>: no declared width, merge kernels
+            if self.width:
+                raise ValueError("batches with 64-bit ids have no declared width")
+            check(self._lib.sdrb_batch_create64(self.device, self.data_kind, C.byref(self._h)))
+        elif self.id_bits == 32:
+            check(self._lib.sdrb_batch_create(self.device, self.width, self.data_kind, C.byref(self._h)))
+        else:
+            raise ValueError("id_bits must be 32 or 64")
         self.n_rows = 0
         self.nnz = 0
         self.max_row_len = 0
@@ -92,7 +100,8 @@ class SDRBatch:
     def from_csr(cls, offsets, ids, data=None, *, width: int = 0, device: int = 0, stream=None, kind=None):
         """``kind``: "empty" / "unit" / "arith"; by default "unit" when payloads are given (UnitData,
         values in [0,1]); "arith" takes any finite float (ArithData<float>, for :meth:`inner`)."""
-        b = cls(device, width, kind if kind is not None else ("unit" if data is not None else "empty"))
+        id_bits = 64 if np.asarray(ids).dtype == np.int64 else 32     # int64 arrays make a 64-bit batch
+        b = cls(device, width, kind if kind is not None else ("unit" if data is not None else "empty"), id_bits)
         b.upload(offsets, ids, data, stream=stream)
         return b
 
@@ -103,7 +112,7 @@ class SDRBatch:
 
     def upload(self, offsets, ids, data=None, *, stream=None) -> None:
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
-        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int64 if self.id_bits == 64 else np.int32)
         if off.ndim != 1 or off.size < 1:
             raise ValueError("offsets must be a 1-d array with n_rows+1 entries")
         if int(off[-1]) != ids.size:
@@ -119,7 +128,8 @@ class SDRBatch:
         elif data is not None:
             raise ValueError("EmptyData batch takes no payloads")
         n_rows = off.size - 1
-        check(self._lib.sdrb_batch_upload_csr(self._h, n_rows, off.ctypes.data_as(C.c_void_p),
+        upload = self._lib.sdrb_batch_upload_csr64 if self.id_bits == 64 else self._lib.sdrb_batch_upload_csr
+        check(upload(self._h, n_rows, off.ctypes.data_as(C.c_void_p),
                                               ids.ctypes.data_as(C.c_void_p), dptr,
                                               _stream_handle(self.device, stream)))
         self.n_rows = n_rows
@@ -353,10 +363,11 @@ class SDRBatch:
                                            C.byref(total), s))
         n = int(total.value)
         # buffers keep at least one element so an empty result still has a valid pointer
-        ids_buf = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        ids_buf = torch.empty(max(n, 1), dtype=torch.int64 if self.id_bits == 64 else torch.int32, device=dev)
         this_kind = other.data_kind if swap else self.data_kind
         data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if this_kind == DATA_UNIT else None
-        check(self._lib.sdrb_elem_op_fill(self._h, other._h, op, flags, offsets.data_ptr(),
+        fill = self._lib.sdrb_elem_op_fill64 if self.id_bits == 64 else self._lib.sdrb_elem_op_fill
+        check(fill(self._h, other._h, op, flags, offsets.data_ptr(),
                                           ids_buf.data_ptr(),
                                           data_buf.data_ptr() if data_buf is not None else None, s))
         ids = ids_buf[:n]

@@ -73,7 +73,7 @@ int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
     if (b->owns_storage && b->d_offsets && b->cap_rows >= n_rows && b->cap_nnz >= nnz) return SDRB_OK;
     free_batch_storage(b);
     SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
-    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_ids), nnz * sizeof(int32_t)));
+    if (nnz) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_ids), nnz * (b->id_bits == 64 ? 8u : 4u)));
     if (nnz && unit) SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_data), nnz * sizeof(float)));
     b->cap_rows = n_rows;
     b->cap_nnz = nnz;
@@ -143,6 +143,19 @@ int check_pair(const sdrb_batch* a, const sdrb_batch* b, int op) {
     if (!a->d_offsets || !b->d_offsets) {
         set_error("batch has no uploaded rows");
         return SDRB_ERR_INVALID_ARG;
+    }
+    if (a->id_bits != b->id_bits) {
+        set_error("one batch holds 32-bit ids and the other 64-bit ids");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    return SDRB_OK;
+}
+
+// everything except the per-pair merge kernels reads 32-bit ids
+int check_ids32(const sdrb_batch* a, const sdrb_batch* b, const char* what) {
+    if ((a && a->id_bits != 32) || (b && b->id_bits != 32)) {
+        set_error("%s does not take batches with 64-bit ids", what);
+        return SDRB_ERR_UNSUPPORTED;
     }
     return SDRB_OK;
 }
@@ -230,10 +243,87 @@ int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out
     return SDRB_OK;
 }
 
+int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out) {
+    if (data_kind == SDRB_DATA_ARITH) {
+        set_error("sdrb_batch_create64: EmptyData or UnitData payloads only");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const int rc = sdrb_batch_create(device, 0, data_kind, out);
+    if (rc == SDRB_OK) (*out)->id_bits = 64;
+    return rc;
+}
+
+int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
+                            const int64_t* ids, const float* data, void* stream) {
+    if (!batch || !row_offsets || batch->id_bits != 64) {
+        set_error("sdrb_batch_upload_csr64: null argument or not a 64-bit batch");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (row_offsets[0] != 0) {
+        set_error("row_offsets[0] must be 0");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const uint64_t nnz = row_offsets[n_rows];
+    if (nnz > 0xFFFFFFFFull || n_rows > 0xFFFFFFFEull) {
+        set_error("batch too large for 32-bit offsets");
+        return SDRB_ERR_OVERFLOW;
+    }
+    const bool payload = has_payload(batch);
+    if (nnz && (!ids || (payload && !data))) {
+        set_error("ids (and payloads of a UnitData batch) must not be null");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    std::vector<uint32_t> off32(n_rows + 1);
+    uint32_t max_len = 0;
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        const uint64_t lo = row_offsets[r], hi = row_offsets[r + 1];
+        if (hi < lo || hi > nnz) {
+            set_error("row_offsets not monotone at row %llu", (unsigned long long)r);
+            return SDRB_ERR_INVALID_ARG;
+        }
+        off32[r] = (uint32_t)lo;
+        if (hi - lo > max_len) max_len = (uint32_t)(hi - lo);
+        for (uint64_t k = lo + 1; k < hi; ++k)
+            if (ids[k] <= ids[k - 1]) {
+                set_error("row %llu is not strictly ascending", (unsigned long long)r);
+                return SDRB_ERR_NOT_ASCENDING;
+            }
+    }
+    off32[n_rows] = (uint32_t)nnz;
+    if (payload)
+        for (uint64_t k = 0; k < nnz; ++k)
+            if (!(data[k] >= 0.0f && data[k] <= 1.0f)) {
+                set_error("UnitData payload %g at element %llu is outside [0,1]", (double)data[k], (unsigned long long)k);
+                return SDRB_ERR_PAYLOAD_RANGE;
+            }
+    DeviceGuard guard(batch->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", batch->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = reserve_batch_storage(batch, n_rows, nnz);
+    if (rc != SDRB_OK) return rc;
+    SDRB_HIP(hipMemcpyAsync(batch->d_offsets, off32.data(), (n_rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if (nnz && payload) SDRB_HIP(hipMemcpyAsync(batch->d_data, data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    batch->n_rows = n_rows;
+    batch->nnz = nnz;
+    batch->max_row_len = max_len;
+    batch->min_id = 0;
+    batch->max_id = -1;
+    return SDRB_OK;
+}
+
 int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
                           const int32_t* ids, const float* data, void* stream) {
     if (!batch || !row_offsets) {
         set_error("sdrb_batch_upload_csr: null argument");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (batch->id_bits != 32) {
+        set_error("this batch holds 64-bit ids: use sdrb_batch_upload_csr64");
         return SDRB_ERR_INVALID_ARG;
     }
     if (row_offsets[0] != 0) {
@@ -339,6 +429,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
         set_error("sdrb_batch_upload_device_csr: null argument");
         return SDRB_ERR_INVALID_ARG;
     }
+    if (check_ids32(batch, nullptr, "sdrb_batch_upload_device_csr") != SDRB_OK) return SDRB_ERR_UNSUPPORTED;
     if (n_rows > 0xFFFFFFFEull) {
         set_error("too many rows for 32-bit offsets");
         return SDRB_ERR_OVERFLOW;
@@ -414,6 +505,7 @@ int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz
         set_error("sdrb_batch_adopt_device_csr: null argument");
         return SDRB_ERR_INVALID_ARG;
     }
+    if (check_ids32(batch, nullptr, "sdrb_batch_adopt_device_csr") != SDRB_OK) return SDRB_ERR_UNSUPPORTED;
     if (nnz > 0xFFFFFFFFull || n_rows > 0xFFFFFFFEull) {
         set_error("batch too large for 32-bit offsets");
         return SDRB_ERR_OVERFLOW;
@@ -468,6 +560,7 @@ int sdrb_batch_export_device_csr(const sdrb_batch* batch, uint32_t* row_offsets,
         set_error("sdrb_batch_export_device_csr: null argument or empty handle");
         return SDRB_ERR_INVALID_ARG;
     }
+    if (check_ids32(batch, nullptr, "sdrb_batch_export_device_csr") != SDRB_OK) return SDRB_ERR_UNSUPPORTED;
     DeviceGuard guard(batch->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     SDRB_HIP(hipMemcpyAsync(row_offsets, batch->d_offsets, (batch->n_rows + 1) * sizeof(uint32_t),
@@ -520,7 +613,7 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_INVALID_ARG;
     }
     const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
-    const bool can_bitslice = id_only(a, b, op, swap) && bitslice_applicable(a, b);
+    const bool can_bitslice = a->id_bits == 32 && id_only(a, b, op, swap) && bitslice_applicable(a, b);
     if ((flags & SDRB_FLAG_FORCE_BITSLICE) && !can_bitslice) {
         set_error("bit-sliced kernel requested but not applicable to these batches/op");
         return SDRB_ERR_UNSUPPORTED;
@@ -531,9 +624,9 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (rowwise) return launch_size_merge(a, b, op, swap, out, ld_out, true, s);
+    if (rowwise || a->id_bits == 64) return launch_size_merge(a, b, op, swap, out, ld_out, rowwise, s);
     if (flags & SDRB_FLAG_FORCE_POPCOUNT) {
-        if (!id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
+        if (a->id_bits != 32 || !id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
             set_error("popcount kernel requested but not applicable to these batches/op");
             return SDRB_ERR_UNSUPPORTED;
         }
@@ -557,6 +650,7 @@ int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
         set_error("sdrb_batch_transpose: null, identical or empty handles");
         return SDRB_ERR_INVALID_ARG;
     }
+    if (check_ids32(src, dst, "sdrb_batch_transpose") != SDRB_OK) return SDRB_ERR_UNSUPPORTED;
     if (src->width <= 0 || src->device != dst->device || src->data_kind != dst->data_kind) {
         set_error("sdrb_batch_transpose: src needs a declared width; dst the same device and payload kind");
         return SDRB_ERR_INVALID_ARG;
@@ -592,6 +686,10 @@ int check_queries(const sdrb_batch* b, uint64_t n, const int32_t* lo, const int3
     if (!b || !b->d_offsets) {
         sdrb::set_error("null batch handle or no uploaded rows");
         return SDRB_ERR_INVALID_ARG;
+    }
+    if (b->id_bits != 32) {
+        sdrb::set_error("range and point queries do not take batches with 64-bit ids");
+        return SDRB_ERR_UNSUPPORTED;
     }
     if (n && (!lo || (ranges && !hi))) {
         sdrb::set_error("query arrays are null");
@@ -686,6 +784,7 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
                void* stream) {
     (void)flags;
     int rc = check_pair(a, b, SDRB_OP_AND);
+    if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_inner");
     if (rc != SDRB_OK) return rc;
     if (a->data_kind != SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_UNIT) {
         set_error("sdrb_inner takes an ArithData batch and an ArithData or EmptyData batch");
@@ -708,6 +807,7 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
     int rc = check_pair(a, b, SDRB_OP_AND);
+    if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_allpairs_topk");
     if (rc != SDRB_OK) return rc;
     if (k == 0 || !out_counts || !out_rows) {
         set_error("sdrb_allpairs_topk: k is 0 or an output is null");
@@ -787,9 +887,16 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
     return SDRB_OK;
 }
 
-int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
-                      const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
+namespace {
+int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, const uint32_t* out_offsets,
+                     void* out_ids_any, int want_bits, float* out_data, void* stream) {
     int rc = check_pair(a, b, op);
+    if (rc == SDRB_OK && a->id_bits != want_bits) {
+        set_error("these batches hold %d-bit ids: use %s", a->id_bits,
+                  a->id_bits == 64 ? "sdrb_elem_op_fill64" : "sdrb_elem_op_fill");
+        rc = SDRB_ERR_INVALID_ARG;
+    }
+    int32_t* out_ids = static_cast<int32_t*>(out_ids_any);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
     if (rc != SDRB_OK) return rc;
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
@@ -810,14 +917,25 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise) {
+    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32) {
         if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
         if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && a->n_rows >= 4 && mask_table_applicable(a, b))
             return launch_elem_mask_table(a, b, swap, out_offsets, out_ids, out_data, s);
         if (unit_table_fill_applicable(a, b, op, swap))
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }
-    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids, out_data, rowwise, s);
+    return launch_elem_fill(a, b, op, swap, out_offsets, out_ids_any, out_data, rowwise, s);
+}
+}  // namespace
+
+int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                      const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
+    return elem_op_fill_any(a, b, op, flags, out_offsets, out_ids, 32, out_data, stream);
+}
+
+int sdrb_elem_op_fill64(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                        const uint32_t* out_offsets, int64_t* out_ids, float* out_data, void* stream) {
+    return elem_op_fill_any(a, b, op, flags, out_offsets, out_ids, 64, out_data, stream);
 }
 
 int sdrb_malloc(int device, size_t bytes, void** ptr) {

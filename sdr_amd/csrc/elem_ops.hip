@@ -82,12 +82,12 @@ int scan_level(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t stream) {
     return SDRB_OK;
 }
 
-template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+template <typename ID, int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
 __global__ __launch_bounds__(kBlock) void k_elem_fill(
-    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids,
+    const uint32_t* __restrict__ a_off, const ID* __restrict__ a_ids,
     const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
-    const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
-    const uint32_t* __restrict__ out_off, int32_t* __restrict__ out_ids,
+    const ID* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
+    const uint32_t* __restrict__ out_off, ID* __restrict__ out_ids,
     float* __restrict__ out_data, uint32_t rowwise) {
     constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
     constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
@@ -97,17 +97,17 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
     if (j >= nb) return;
     const uint32_t b_beg = b_off[j];
     const uint32_t lb = b_off[j + 1] - b_beg;
-    const int32_t* bi = b_ids + b_beg;
+    const ID* bi = b_ids + b_beg;
     const float* bd = B_UNIT ? b_data + b_beg : nullptr;
 
     // all pairs, or row-wise: row j of A only (result j)
     for (uint64_t i = rowwise ? j : blockIdx.y; i < na; i += rowwise ? na : gridDim.y) {
         const uint32_t a_beg = a_off[i];
         const uint32_t la = a_off[i + 1] - a_beg;
-        const int32_t* ai = a_ids + a_beg;
+        const ID* ai = a_ids + a_beg;
         const float* ad = A_UNIT ? a_data + a_beg : nullptr;
         uint32_t w = out_off[rowwise ? j : i * nb + j];
-        auto emit = [&](int32_t id, float d) {
+        auto emit = [&](ID id, float d) {
             out_ids[w] = id;
             if constexpr (THIS_UNIT) out_data[w] = d;
             ++w;
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
         };
         uint32_t pa = 0, pb = 0;
         while (pa < la && pb < lb) {
-            const int32_t x = ai[pa];
-            const int32_t y = bi[pb];
+            const ID x = ai[pa];
+            const ID y = bi[pb];
             if (x == y) {
                 const float va = A_UNIT ? ad[pa] : 0.0f;
                 const float vb = B_UNIT ? bd[pb] : 0.0f;
@@ -159,7 +159,7 @@ struct FillArgs {
     const sdrb_batch* a;
     const sdrb_batch* b;
     const uint32_t* out_off;
-    int32_t* out_ids;
+    void* out_ids;
     float* out_data;
     bool rowwise;
     hipStream_t stream;
@@ -169,9 +169,16 @@ template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
 void launch(const FillArgs& g) {
     const uint32_t gx = (uint32_t)((g.b->n_rows + kBlock - 1) / kBlock);
     const uint32_t gy = g.rowwise ? 1u : (uint32_t)(g.a->n_rows < 65535 ? g.a->n_rows : 65535);
-    hipLaunchKernelGGL((k_elem_fill<OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
-                       g.a->d_offsets, g.a->d_ids, g.a->d_data, g.a->n_rows, g.b->d_offsets,
-                       g.b->d_ids, g.b->d_data, g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.rowwise ? 1u : 0u);
+    if (g.a->id_bits == 64)
+        hipLaunchKernelGGL((k_elem_fill<long long, OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
+                           g.a->d_offsets, reinterpret_cast<const long long*>(g.a->d_ids), g.a->d_data, g.a->n_rows,
+                           g.b->d_offsets, reinterpret_cast<const long long*>(g.b->d_ids), g.b->d_data, g.b->n_rows,
+                           g.out_off, static_cast<long long*>(g.out_ids), g.out_data, g.rowwise ? 1u : 0u);
+    else
+        hipLaunchKernelGGL((k_elem_fill<int32_t, OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
+                           g.a->d_offsets, g.a->d_ids, g.a->d_data, g.a->n_rows, g.b->d_offsets, g.b->d_ids,
+                           g.b->d_data, g.b->n_rows, g.out_off, static_cast<int32_t*>(g.out_ids), g.out_data,
+                           g.rowwise ? 1u : 0u);
 }
 
 template <int OP, bool SWAP>
@@ -206,7 +213,7 @@ int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_
 }
 
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
-                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data, bool rowwise,
+                     const uint32_t* out_offsets, void* out_ids, float* out_data, bool rowwise,
                      hipStream_t stream) {
     FillArgs g{a, b, out_offsets, out_ids, out_data, rowwise, stream};
     switch (op) {

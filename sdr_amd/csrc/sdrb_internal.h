@@ -13,6 +13,7 @@ struct sdrb_batch {
     int device = 0;
     int32_t width = 0;     // 0 = undeclared
     int data_kind = SDRB_DATA_EMPTY;
+    int id_bits = 32;      // 64: d_ids points at int64 ids (merge kernels only; min_id/max_id unused)
     uint64_t n_rows = 0;
     uint64_t nnz = 0;
     uint32_t max_row_len = 0;
@@ -66,13 +67,15 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
 
 // size_merge.hip ------------------------------------------------------------------
 // rowwise: result j = A_j.op(B_j) for two batches of equal length, out[j]
+// (both batches hold ids of the same width: 32 or 64 bits)
 int launch_size_merge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                       uint32_t* out, uint64_t ld_out, bool rowwise, hipStream_t stream);
 
 // elem_ops.hip --------------------------------------------------------------------
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream);
+// out_ids: int32 ids, or int64 ids when the batches hold 64-bit ids
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
-                     const uint32_t* out_offsets, int32_t* out_ids, float* out_data, bool rowwise,
+                     const uint32_t* out_offsets, void* out_ids, float* out_data, bool rowwise,
                      hipStream_t stream);
 
 // elem_bitmap.hip ------------------------------------------------------------------

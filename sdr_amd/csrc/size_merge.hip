@@ -14,11 +14,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
-template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+template <typename ID, int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
 __global__ __launch_bounds__(kBlock) void k_size_merge(
-    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids,
+    const uint32_t* __restrict__ a_off, const ID* __restrict__ a_ids,
     const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
-    const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
+    const ID* __restrict__ b_ids, const float* __restrict__ b_data, uint64_t nb,
     uint32_t* __restrict__ out, uint64_t ld_out, uint32_t rowwise) {
     constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
     constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void k_size_merge(
     if (j >= nb) return;
     const uint32_t b_beg = b_off[j];
     const uint32_t lb = b_off[j + 1] - b_beg;
-    const int32_t* bi = b_ids + b_beg;
+    const ID* bi = b_ids + b_beg;
     const float* bd = B_UNIT ? b_data + b_beg : nullptr;
 
     // all pairs: this lane's row against every row of A the block column visits;
@@ -34,12 +34,12 @@ __global__ __launch_bounds__(kBlock) void k_size_merge(
     for (uint64_t i = rowwise ? j : blockIdx.y; i < na; i += rowwise ? na : gridDim.y) {
         const uint32_t a_beg = a_off[i];
         const uint32_t la = a_off[i + 1] - a_beg;
-        const int32_t* ai = a_ids + a_beg;
+        const ID* ai = a_ids + a_beg;
         const float* ad = A_UNIT ? a_data + a_beg : nullptr;
         uint32_t pa = 0, pb = 0, m = 0, k = 0;
         while (pa < la && pb < lb) {
-            const int32_t x = ai[pa];
-            const int32_t y = bi[pb];
+            const ID x = ai[pa];
+            const ID y = bi[pb];
             if (x == y) {
                 const float va = A_UNIT ? ad[pa] : 0.0f;
                 const float vb = B_UNIT ? bd[pb] : 0.0f;
@@ -65,9 +65,15 @@ void launch(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld
             hipStream_t stream) {
     const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
     const uint32_t gy = rowwise ? 1u : (uint32_t)(a->n_rows < 65535 ? a->n_rows : 65535);
-    hipLaunchKernelGGL((k_size_merge<OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, stream,
-                       a->d_offsets, a->d_ids, a->d_data, a->n_rows, b->d_offsets, b->d_ids,
-                       b->d_data, b->n_rows, out, ld_out, rowwise ? 1u : 0u);
+    if (a->id_bits == 64)   // ids of the reference's `long` element type (src/fuzz.cpp:413-423)
+        hipLaunchKernelGGL((k_size_merge<long long, OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, stream,
+                           a->d_offsets, reinterpret_cast<const long long*>(a->d_ids), a->d_data, a->n_rows,
+                           b->d_offsets, reinterpret_cast<const long long*>(b->d_ids), b->d_data, b->n_rows, out,
+                           ld_out, rowwise ? 1u : 0u);
+    else
+        hipLaunchKernelGGL((k_size_merge<int32_t, OP, SWAP, A_UNIT, B_UNIT>), dim3(gx, gy), dim3(kBlock), 0, stream,
+                           a->d_offsets, a->d_ids, a->d_data, a->n_rows, b->d_offsets, b->d_ids, b->d_data,
+                           b->n_rows, out, ld_out, rowwise ? 1u : 0u);
 }
 
 template <int OP, bool SWAP>

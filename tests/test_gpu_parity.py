@@ -438,3 +438,43 @@ def test_mask_table_kernel_many_tiles_and_groups(name):
     w_off, w_ids, w_data = oracle.port().elem_op(AND, a, t)
     assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
                           util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_batches_with_64_bit_ids_vs_reference(golden, name):
+    """Rows with `long` ids (SDRElem<long, ...>, src/fuzz.cpp:413-423), far outside the 32-bit range:
+    sizes and elements (int64 ids, payload bits) against what the reference itself returned."""
+    g = golden("long_ids.npz")
+
+    def side(s):
+        key = f"{name}_{s}_data"
+        return g[f"{name}_{s}_off"], g[f"{name}_{s}_ids"], (g[key] if key in g.files else None)
+    t, a = SDRBatch.from_csr(*side("t")), SDRBatch.from_csr(*side("a"))
+    assert t.id_bits == 64 and a.id_bits == 64
+    for op in range(4):
+        assert np.array_equal(gpu_sizes(op, t, a), g[f"{name}_size{op}"]), op
+        off, ids, data = gpu_elems(op, t, a)
+        assert ids.dtype == np.int64
+        assert np.array_equal(off, g[f"{name}_off{op}"]) and np.array_equal(ids, g[f"{name}_ids{op}"]), op
+        if f"{name}_data{op}" in g.files:
+            assert np.array_equal(data.view(np.uint32), g[f"{name}_data{op}"].view(np.uint32)), op
+        else:
+            assert data is None
+        # the swap flag evaluates a.op(t) into the same layout
+        assert np.array_equal(gpu_sizes(op, a, t, swap=True), g[f"{name}_size{op}"].T), op
+
+
+@pytest.mark.gpu
+def test_64_bit_batches_are_refused_where_not_supported():
+    rng = np.random.default_rng(12)
+    off, ids, _ = util.ragged_rows(rng, 20, 100, 10)
+    wide = SDRBatch.from_csr(off, ids.astype(np.int64) * (1 << 35))
+    narrow = SDRBatch.from_csr(off, ids)
+    for call in (lambda: wide.ands(narrow), lambda: wide.allpairs_topk(wide, 4), lambda: wide.range_size([0], [5]),
+                 lambda: wide.to_wire()):
+        with pytest.raises(sdr_amd.SdrbError):
+            call()
+    with pytest.raises(sdr_amd.SdrbError) as e:
+        SDRBatch.from_csr(np.array([0, 2], np.uint64), np.array([5, 5], np.int64))
+    assert e.value.code == -2

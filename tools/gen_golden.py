@@ -216,6 +216,36 @@ def gen_queries():
     np.savez_compressed(os.path.join(OUT, "queries.npz"), **out)
 
 
+def gen_long_ids():
+    """Size and element ops on rows with `long` ids (SDRElem<long, ...>, src/fuzz.cpp:413-423): ids far
+    outside the 32-bit range, all four payload pairings; outputs of the reference itself."""
+    rng = np.random.default_rng(FUZZ_SEED + 17)
+    out = {}
+    universe = np.sort(rng.choice(np.arange(-2 ** 40, 2 ** 40, 2 ** 33 + 12345, dtype=np.int64), 90, replace=False))
+    for name, (tu, au) in {"EE": (False, False), "UU": (True, True), "UE": (True, False), "EU": (False, True)}.items():
+        t32 = util.ragged_rows(rng, 24, 90, 40, tu)
+        a32 = util.ragged_rows(rng, 60, 90, 40, au)
+        t = (t32[0], universe[t32[1]], t32[2])
+        a = (a32[0], universe[a32[1]], a32[2])
+        for side, csr in (("t", t), ("a", a)):
+            out[f"{name}_{side}_off"], out[f"{name}_{side}_ids"] = csr[0], csr[1]
+            if csr[2] is not None:
+                out[f"{name}_{side}_data"] = csr[2]
+        for op in range(4):
+            out[f"{name}_size{op}"] = oracle.reference(debug=True).ref_op64(op, False, t, a)
+            off, ids, data = oracle.reference(debug=True).ref_op64(op, True, t, a)
+            out[f"{name}_off{op}"], out[f"{name}_ids{op}"] = off, ids
+            if data is not None:
+                out[f"{name}_data{op}"] = data
+            # ids only matter through their order: the 32-bit restatement on the ranks agrees
+            want = oracle.port().size_op(op, oracle.Batch(*t32), oracle.Batch(*a32))
+            assert np.array_equal(want, out[f"{name}_size{op}"])
+            w_off, w_ids, w_data = oracle.port().elem_op(op, oracle.Batch(*t32), oracle.Batch(*a32))
+            assert np.array_equal(w_off, off) and np.array_equal(universe[w_ids], ids)
+            assert (w_data is None and data is None) or np.array_equal(w_data.view(np.uint32), data.view(np.uint32))
+    np.savez_compressed(os.path.join(OUT, "long_ids.npz"), **out)
+
+
 def gen_transpose():
     """SDR::transpose (SDR.hpp:1807-1826) on a matrix stored as batch rows.  The reference emits every
     column's elements in the pop order of its priority queue (MatrixUtils.hpp:13-75), which for equal
@@ -240,6 +270,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if not oracle.have_reference():
         sys.exit("oracle/_ref is not built: this script needs /root/reference (make -C oracle)")
+    if sys.argv[1:] == ["long_ids"]:
+        gen_long_ids()
+        return
     if sys.argv[1:] == ["transpose"]:
         gen_transpose()
         return
@@ -252,6 +285,7 @@ def main():
     gen_inner()
     gen_queries()
     gen_transpose()
+    gen_long_ids()
     gen_fuzz_sizes()
     gen_fuzz_elems()
     gen_mini("mini_2048_40.npz", 8, 4096, 2048, 40, False)
