@@ -233,8 +233,9 @@ int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t 
     if (!ws) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemsetAsync(ws, 0, table_bytes + len_bytes, stream));
     if (b->n_rows) {
-        hipLaunchKernelGGL(k_build_table, dim3((uint32_t)b->n_rows), dim3(64), 0, stream, b->d_offsets, b->d_ids,
-                           (int32_t)wcap, (uint32_t)wcap, reinterpret_cast<u64*>(ws),
+        hipLaunchKernelGGL(k_build_table, dim3((uint32_t)((b->n_rows + kBuildRows - 1) / kBuildRows)), dim3(64 * kBuildRows), 0,
+                           stream, b->d_offsets, b->d_ids, (uint32_t)b->n_rows, (int32_t)wcap, (uint32_t)wcap,
+                           reinterpret_cast<u64*>(ws),
                            reinterpret_cast<uint32_t*>(ws + table_bytes));
         SDRB_HIP(hipGetLastError());
     }
@@ -244,6 +245,7 @@ int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t 
     // the key's row range; every split keeps its own lists, merged afterwards
     const uint32_t gx = (uint32_t)((a->n_rows + kBlock - 1) / kBlock);
     uint32_t splits = gx >= 768 ? 1u : (768u + gx - 1) / gx;
+    if (splits > 32u) splits = 32u;              // the merge kernel holds 32 lists of 16 keys per row
     if (splits > g.ntiles) splits = g.ntiles ? g.ntiles : 1u;
     const uint32_t max_tiles = kTopkMaxSplitRows / kTileRows;
     if ((g.ntiles + splits - 1) / splits > max_tiles) splits = (g.ntiles + max_tiles - 1) / max_tiles;

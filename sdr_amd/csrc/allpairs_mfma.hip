@@ -320,35 +320,50 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
     }
 }
 
-// one thread per row i: k rounds of "largest key below the previous one" over all partial lists
+// One wave per row i: every lane keeps up to 8 of the row's partial-list keys (widened to
+// count << 32 | ~j) in registers; k rounds of "largest key below the previous one", each a lane-local
+// maximum followed by a wave-wide maximum.
+constexpr int kMergeKeysPerLane = 8;   // 64 lanes x 8 = 512 keys = 8 splits x 4 lists x 16 entries at most
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_merge_topk(const int* __restrict__ partial, uint32_t na, uint32_t splits,
                                                     uint32_t per_split, unsigned long long rows_per_split, uint32_t k,
                                                     uint32_t* __restrict__ out_counts, int32_t* __restrict__ out_rows) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= na) return;
-    const int* mine = partial + (uint64_t)i * splits * per_split;
+    const uint32_t n_keys = splits * per_split;
+    const int* mine = partial + (uint64_t)i * n_keys;
+    unsigned long long wide[kMergeKeysPerLane];
+#pragma unroll
+    for (int s = 0; s < kMergeKeysPerLane; ++s) {
+        const uint32_t e = lane + 64u * s;
+        const int key = e < n_keys ? mine[e] : 0;
+        const unsigned long long j_base = (e / per_split) * rows_per_split;
+        const unsigned long long count = (unsigned long long)(key >> kKeyShift);
+        const unsigned long long j = j_base + (unsigned long long)(kLowMask - (key & kLowMask));
+        wide[s] = key > 0 ? (count << 32) | (0xFFFFFFFFull - j) : 0ull;
+    }
     unsigned long long prev = ~0ull;
     for (uint32_t t = 0; t < k; ++t) {
         unsigned long long best = 0;
-        for (uint32_t sp = 0; sp < splits; ++sp) {
-            const unsigned long long j_base = sp * rows_per_split;
-            for (uint32_t e = 0; e < per_split; ++e) {
-                const int key = mine[sp * per_split + e];
-                if (key <= 0) continue;
-                const unsigned long long count = (unsigned long long)(key >> kKeyShift);
-                const unsigned long long j = j_base + (unsigned long long)(kLowMask - (key & kLowMask));
-                const unsigned long long wide = (count << 32) | (0xFFFFFFFFull - j);
-                if (wide < prev && wide > best) best = wide;
-            }
+#pragma unroll
+        for (int s = 0; s < kMergeKeysPerLane; ++s)
+            if (wide[s] < prev && wide[s] > best) best = wide[s];
+        best = wave_max_u64(best);
+        if (lane == 0) {
+            out_counts[(uint64_t)i * k + t] = best ? (uint32_t)(best >> 32) : 0u;
+            out_rows[(uint64_t)i * k + t] = best ? (int32_t)(0xFFFFFFFFull - (best & 0xFFFFFFFFull)) : -1;
         }
-        if (best == 0) {
-            out_counts[(uint64_t)i * k + t] = 0;
-            out_rows[(uint64_t)i * k + t] = -1;
-        } else {
-            out_counts[(uint64_t)i * k + t] = (uint32_t)(best >> 32);
-            out_rows[(uint64_t)i * k + t] = (int32_t)(0xFFFFFFFFull - (best & 0xFFFFFFFFull));
-            prev = best;
-        }
+        if (best) prev = best;
+        else prev = 0;   // nothing left: every further slot is empty
     }
 }
 
@@ -419,7 +434,11 @@ int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint
 int launch_merge_topk(const int* partial, uint32_t na, uint32_t splits, uint32_t lists_per_split,
                       uint64_t rows_per_split, uint32_t k, uint32_t* out_counts, int32_t* out_rows,
                       hipStream_t stream) {
-    hipLaunchKernelGGL(k_merge_topk, dim3((na + 255) / 256), dim3(256), 0, stream, partial, na, splits,
+    if ((uint64_t)splits * lists_per_split * kTopkList > 64u * kMergeKeysPerLane) {
+        set_error("too many partial top-k lists per row (%u splits)", splits);
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_merge_topk, dim3((na + 3) / 4), dim3(256), 0, stream, partial, na, splits,
                        lists_per_split * kTopkList, (unsigned long long)rows_per_split, k, out_counts, out_rows);
     SDRB_HIP(hipGetLastError());
     return SDRB_OK;

@@ -23,18 +23,22 @@ constexpr int kBlock = SDRB_BS_BLOCK;  // threads per block = rows of B per bloc
 constexpr int kMinWaves = SDRB_BS_MIN_WAVES;  // waves per SIMD the register allocator must allow
 constexpr int kTileRows = 64;  // rows of A per table tile = bits of one table word
 
-__global__ __launch_bounds__(64) void k_build_table(const uint32_t* __restrict__ a_off,
-                                                     const int32_t* __restrict__ a_ids,
-                                                     int32_t width, uint32_t tile_words,
-                                                     u64* __restrict__ table,
-                                                     uint32_t* __restrict__ a_len) {
-    const uint64_t i = blockIdx.x;
+// one wave per row, kBuildRows rows per block: launch with ceil(n_rows / kBuildRows) blocks of 64 * kBuildRows threads
+constexpr int kBuildRows = 4;
+__global__ __launch_bounds__(64 * kBuildRows) void k_build_table(const uint32_t* __restrict__ a_off,
+                                                                  const int32_t* __restrict__ a_ids,
+                                                                  uint32_t n_rows, int32_t width, uint32_t tile_words,
+                                                                  u64* __restrict__ table,
+                                                                  uint32_t* __restrict__ a_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBuildRows + (threadIdx.x >> 6);
+    if (i >= n_rows) return;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t beg = a_off[i];
     const uint32_t len = a_off[i + 1] - beg;
-    if (threadIdx.x == 0) a_len[i] = len;
+    if (lane == 0) a_len[i] = len;
     u64* tile = table + (i / kTileRows) * (uint64_t)tile_words;
     const u64 bit = 1ull << (i % kTileRows);
-    for (uint32_t k = threadIdx.x; k < len; k += 64) {
+    for (uint32_t k = lane; k < len; k += 64) {
         const int32_t id = a_ids[beg + k];
         // ids outside B's declared width cannot match any id of B
         if ((uint32_t)id < (uint32_t)width) atomicOr(&tile[id], bit);

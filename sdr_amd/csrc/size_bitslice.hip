@@ -245,8 +245,8 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     SDRB_HIP(hipMemsetAsync(ws, 0, table_bytes + len_bytes, stream));
     u64* table = reinterpret_cast<u64*>(ws);
     uint32_t* a_len = reinterpret_cast<uint32_t*>(ws + table_bytes);
-    hipLaunchKernelGGL(k_build_table, dim3((uint32_t)a->n_rows), dim3(64), 0, stream, a->d_offsets,
-                       a->d_ids, b->width, (uint32_t)plan.wcap, table, a_len);
+    hipLaunchKernelGGL(k_build_table, dim3((uint32_t)((a->n_rows + kBuildRows - 1) / kBuildRows)), dim3(64 * kBuildRows), 0,
+                       stream, a->d_offsets, a->d_ids, (uint32_t)a->n_rows, b->width, (uint32_t)plan.wcap, table, a_len);
     SDRB_HIP(hipGetLastError());
     g.table = table;
     g.a_len = a_len;

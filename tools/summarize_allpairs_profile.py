@@ -9,11 +9,14 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "k_allpairs_mfma"
+KERNEL = "k_allpairs_mfma"      # overridden by a second argument (e.g. k_allpairs_bitslice)
 
 
 def main():
+    global KERNEL
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    if len(sys.argv) > 2:
+        KERNEL = sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", f"prof_ap_{tag}")
     dst = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0]
