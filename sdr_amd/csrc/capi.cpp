@@ -918,9 +918,10 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32) {
-        if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
-        if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && a->n_rows >= 4 && mask_table_applicable(a, b))
+        // intersections are small: visiting only the matches (mask table) beats enumerating whole bitsets
+        if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && mask_table_applicable(a, b))
             return launch_elem_mask_table(a, b, swap, out_offsets, out_ids, out_data, s);
+        if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
         if (unit_table_fill_applicable(a, b, op, swap))
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }

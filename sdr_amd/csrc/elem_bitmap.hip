@@ -34,10 +34,23 @@ __global__ __launch_bounds__(64) void k_build_bitsets(const uint32_t* __restrict
     }
 }
 
-__device__ __forceinline__ uint32_t popc(uint32_t x) { return __builtin_popcount(x); }
+[[maybe_unused]] __device__ __forceinline__ uint32_t popc(uint32_t x) { return __builtin_popcount(x); }
 __device__ __forceinline__ uint32_t popc(unsigned long long x) { return __builtin_popcountll(x); }
-__device__ __forceinline__ uint32_t lowbit(uint32_t x) { return __builtin_ctz(x); }
+[[maybe_unused]] __device__ __forceinline__ uint32_t lowbit(uint32_t x) { return __builtin_ctz(x); }
 __device__ __forceinline__ uint32_t lowbit(unsigned long long x) { return __builtin_ctzll(x); }
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS traffic): shifts inside
+// rows of 16 lanes, then the last lane of row 0/2 is broadcast into row 1/3 and the last lane of the
+// lower half into the upper half.  Masked-off rows / banks and lanes without a source add 0.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 
 constexpr int kStage = 256;   // ids a wave can stage in LDS for one coalesced copy-out
 constexpr int kQueryChunk = 16;  // rows of A a block visits per row of B (grid.y splits A)
@@ -91,13 +104,8 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap(
             else res = self & ~arg;
             // wave scan of the per-lane popcounts -> position of each lane's first id
             const uint32_t cnt = popc(res);
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d, 64);
-                if (lane >= (uint32_t)d) incl += up;
-            }
-            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t incl = wave_inclusive_scan(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (total == 0) continue;
             const uint32_t base = out_off[(uint64_t)i * nb + j];
             uint32_t pos = incl - cnt;
@@ -121,6 +129,102 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap(
     }
 }
 
+// Two pairs per wave for widths <= 2048: a half-wave of 32 lanes holds the 2048 bits of a pair as
+// 64-bit words, so every wave instruction of the scan / enumerate / copy-out sequence serves two
+// pairs.  The wave's work items are the pairs (i, j) of its tile in j-major order; item p goes to
+// half p & 1 (two rows of A against the same row of B, or -- with a single row of A -- two rows of B).
+// a_bits is the same memory as for the 32-bit kernel (word k of 64 bits = ids 64 k .. 64 k + 63).
+__device__ __forceinline__ uint32_t half_inclusive_scan(uint32_t v) {   // prefix sums inside each 32-lane half
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    return v;
+}
+
+constexpr int kHalfStage = 128;   // ids a half-wave can stage in LDS for one coalesced copy-out
+
+template <int OP, bool SWAP>
+__global__ __launch_bounds__(kBlock) void k_elem_bitmap_pairs(
+    const unsigned long long* __restrict__ a_bits, uint32_t na, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, uint32_t nb, const uint32_t* __restrict__ out_off,
+    int32_t* __restrict__ out_ids, uint32_t rows_per_wave) {
+    using u64 = unsigned long long;
+    __shared__ u64 lds_bits[kWaves][2][32];
+    __shared__ int32_t lds_stage[kWaves][2][kHalfStage];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t half = lane >> 5, hl = lane & 31;
+    const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * rows_per_wave;
+    const uint64_t j_end = j_begin + rows_per_wave < nb ? j_begin + rows_per_wave : nb;
+    const uint32_t i_begin = blockIdx.y * kQueryChunk;
+    const uint32_t i_end = i_begin + kQueryChunk < na ? i_begin + kQueryChunk : na;
+    if (j_begin >= j_end) return;
+    const uint32_t ni = i_end - i_begin;
+    const uint32_t nj = (uint32_t)(j_end - j_begin);
+
+    u64* my_bits = lds_bits[wave][half];
+    int32_t* my_stage = lds_stage[wave][half];
+    uint64_t held_j = ~0ull;   // the row of B whose bitset this half currently holds
+    u64 rbits = 0;
+    uint32_t jj = half / ni, ii = half % ni;   // this half's item, advanced by two items per turn
+    for (uint32_t turn = 0, turns = (nj * ni + 1) / 2; turn < turns; ++turn) {
+        const bool valid = jj < nj;
+        const uint64_t j = j_begin + (valid ? jj : 0);
+        const uint32_t i = i_begin + (valid ? ii : 0);
+        ii += 2;
+        while (ii >= ni) { ii -= ni; ++jj; }
+        // (re)build the half's bitset of row j: zero the words, OR the ids in, read my word back
+        if (__builtin_amdgcn_ballot_w64(valid && j != held_j) != 0) {
+            if (valid && j != held_j) {
+                const uint32_t beg = b_off[j], len = b_off[j + 1] - beg;
+                lds_store(&my_bits[hl], (u64)0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                for (uint32_t k = hl; k < len; k += 32) {
+                    const uint32_t id = (uint32_t)b_ids[beg + k];
+                    __hip_atomic_fetch_or(&my_bits[id >> 6], (u64)1 << (id & 63), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                rbits = lds_load(&my_bits[hl]);
+                held_j = j;
+            }
+        }
+        u64 res = 0;
+        if (valid) {
+            const u64 qbits = a_bits[(uint64_t)i * 32 + hl];
+            const u64 self = SWAP ? rbits : qbits, arg = SWAP ? qbits : rbits;
+            if constexpr (OP == SDRB_OP_AND) res = self & arg;
+            else if constexpr (OP == SDRB_OP_OR) res = self | arg;
+            else if constexpr (OP == SDRB_OP_XOR) res = self ^ arg;
+            else res = self & ~arg;
+        }
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(res);
+        const uint32_t incl = half_inclusive_scan(cnt);
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+        const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if ((t0 | t1) == 0) continue;
+        const uint32_t total = half ? t1 : t0;
+        const uint32_t base = valid ? out_off[(uint64_t)i * nb + j] : 0u;
+        uint32_t pos = incl - cnt;
+        if (t0 <= (uint32_t)kHalfStage && t1 <= (uint32_t)kHalfStage) {
+            while (res) {
+                lds_store(&my_stage[pos++], (int32_t)(hl * 64 + (uint32_t)__builtin_ctzll(res)));
+                res &= res - 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t t = hl; t < total; t += 32) out_ids[base + t] = lds_load(&my_stage[t]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+            pos += base;
+            while (res) {
+                out_ids[pos++] = (int32_t)(hl * 64 + (uint32_t)__builtin_ctzll(res));
+                res &= res - 1;
+            }
+        }
+    }
+}
+
 struct Args {
     const void* a_bits;
     const sdrb_batch* a;
@@ -134,9 +238,15 @@ struct Args {
 
 template <typename WORD, int OP, bool SWAP>
 void launch(const Args& g) {
-    hipLaunchKernelGGL((k_elem_bitmap<WORD, OP, SWAP>), g.grid, dim3(kBlock), 0, g.stream,
-                       static_cast<const WORD*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
-                       g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
+    if constexpr (sizeof(WORD) == 4) {   // widths <= 2048: two pairs per wave on 64-bit words
+        hipLaunchKernelGGL((k_elem_bitmap_pairs<OP, SWAP>), g.grid, dim3(kBlock), 0, g.stream,
+                           static_cast<const unsigned long long*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
+                           g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
+    } else {
+        hipLaunchKernelGGL((k_elem_bitmap<WORD, OP, SWAP>), g.grid, dim3(kBlock), 0, g.stream,
+                           static_cast<const WORD*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
+                           g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
+    }
 }
 
 template <typename WORD, int OP>
