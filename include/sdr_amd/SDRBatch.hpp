@@ -12,7 +12,12 @@
 //     auto db = sdr_amd::SDRBatch::pack(rows.begin(), rows.end(), 0, 2048);
 //     std::vector<uint32_t> counts = q.ands(db).to_host();   // counts[i*db.size()+j] == queries[i].ands(rows[j])
 //     auto r = q.ore(db);                                    // CSR of queries[i].ore(rows[j])
-//     SDR<> first = r.unpack<SDR<>>(0, 0);                   // == queries[0].ore(rows[0])
+//     SDR<> first = sdr_amd::Elements::unpack<SDR<>>(r.to_host(), db.size(), 0, 0);   // == queries[0].ore(rows[0])
+//
+// Element types: ids of 32 or 64 bits (SDRElem<int,...>, SDRElem<long,...>); payloads EmptyData,
+// UnitData or ArithData<float>.  Besides the binary operations: inner (sparse dot products), the
+// row-wise / in-place forms andi ori xori rmi, range and point queries, transpose, all-pairs top-k,
+// and database files (save / load_rows / SDRBatch::from_file).
 //
 // Link with -lsdr_amd (no HIP headers needed here).  Errors become sdr_amd::Error.
 #pragma once
@@ -43,17 +48,34 @@ inline void check(int rc) {
 
 namespace detail {
 
-// A payload with a float value() is treated as UnitData (UnitData.hpp:19); anything else as
-// EmptyData (EmptyData.hpp:18-92).
+// A payload without value() is EmptyData (EmptyData.hpp:18-92).  One with a float value() is
+// UnitData (UnitData.hpp:11-140) or ArithData<float> (ArithData.hpp:11-107); the two are told
+// apart by what defines them here: a zero payload is relevant for ArithData (ArithData.hpp:22-24)
+// and not for UnitData (UnitData.hpp:27-29).
 template <typename D, typename = void>
 struct has_value : std::false_type {};
 template <typename D>
 struct has_value<D, std::void_t<decltype(std::declval<const D&>().value())>> : std::true_type {};
 
+template <typename D>
+int kind_of() {
+    if constexpr (!has_value<D>::value) {
+        return SDRB_DATA_EMPTY;
+    } else {
+        static_assert(std::is_same_v<std::decay_t<decltype(std::declval<const D&>().value())>, float>,
+                      "payload values must be float (UnitData or ArithData<float>)");
+        return D(0.0f).relevant() ? SDRB_DATA_ARITH : SDRB_DATA_UNIT;
+    }
+}
+
 template <typename SDR_t>
 using elem_of = typename SDR_t::value_type;
 template <typename SDR_t>
 using data_of = typename elem_of<SDR_t>::data_type;
+template <typename SDR_t>
+using id_of = typename elem_of<SDR_t>::id_type;
+template <typename SDR_t>
+constexpr bool wide_ids = sizeof(id_of<SDR_t>) > 4;
 
 struct DeviceBuffer {
     int device = 0;
@@ -93,8 +115,9 @@ template <typename Iter>
 void save(Iter first, Iter last, const std::string& path, int32_t width = 0, size_t chunk_rows = 65536) {
     using SDR_t = std::decay_t<decltype(*first)>;
     constexpr bool unit = detail::has_value<detail::data_of<SDR_t>>::value;
+    static_assert(!detail::wide_ids<SDR_t>, "database files hold 32-bit ids");
     sdrb_file_writer* w = nullptr;
-    check(sdrb_file_writer_open(path.c_str(), width, unit ? SDRB_DATA_UNIT : SDRB_DATA_EMPTY, &w));
+    check(sdrb_file_writer_open(path.c_str(), width, detail::kind_of<detail::data_of<SDR_t>>(), &w));
     std::vector<uint64_t> off;
     std::vector<int32_t> ids;
     std::vector<float> data;
@@ -134,7 +157,7 @@ std::vector<SDR_t> load_rows(const std::string& path, uint64_t row_lo = 0, uint6
     check(sdrb_file_row_span(path.c_str(), row_lo, row_hi, &span));
     std::vector<uint64_t> off(row_hi - row_lo + 1);
     std::vector<int32_t> ids(span ? span : 1);
-    std::vector<float> data(kind == SDRB_DATA_UNIT ? (span ? span : 1) : 0);
+    std::vector<float> data(kind != SDRB_DATA_EMPTY ? (span ? span : 1) : 0);
     check(sdrb_file_read_rows(path.c_str(), row_lo, row_hi, off.data(), ids.data(), data.empty() ? nullptr : data.data()));
     std::vector<SDR_t> rows(row_hi - row_lo);
     for (size_t r = 0; r < rows.size(); ++r)
@@ -148,19 +171,23 @@ std::vector<SDR_t> load_rows(const std::string& path, uint64_t row_lo = 0, uint6
     return rows;
 }
 
-// uint32 counts[na][nb] in device memory
-class Counts {
+// T table[na][nb] in device memory
+template <typename T>
+class Table {
  public:
-    Counts(int device, size_t na, size_t nb) : na_(na), nb_(nb), buf_(device, (na * nb ? na * nb : 1) * sizeof(uint32_t)) {}
+    Table(int device, size_t na, size_t nb) : na_(na), nb_(nb), buf_(device, (na * nb ? na * nb : 1) * sizeof(T)) {}
     size_t rows() const { return na_; }
     size_t cols() const { return nb_; }
-    uint32_t* device_ptr() const { return static_cast<uint32_t*>(buf_.ptr); }
-    std::vector<uint32_t> to_host(void* stream = nullptr) const { return buf_.to_host<uint32_t>(na_ * nb_, stream); }
+    T* device_ptr() const { return static_cast<T*>(buf_.ptr); }
+    std::vector<T> to_host(void* stream = nullptr) const { return buf_.to_host<T>(na_ * nb_, stream); }
 
  private:
     size_t na_, nb_;
     detail::DeviceBuffer buf_;
 };
+using Counts = Table<uint32_t>;     // sizes of results
+using Values = Table<float>;        // dot products
+using Positions = Table<int32_t>;   // positions inside rows, -1 = absent
 
 // Per row of the left batch: the k rows of the right batch with the largest id overlap
 // (overlap descending, then row ascending; unused slots hold count 0, row -1)
@@ -186,17 +213,23 @@ class Elements {
     size_t na = 0, nb = 0;
     uint64_t total = 0;
     bool has_data = false;
-    detail::DeviceBuffer offsets, ids, data;
+    int id_bits = 32;                         // ids are int32, or int64 for batches of 64-bit ids
+    detail::DeviceBuffer offsets, ids, data;  // row-wise results: na = 1, one result per column
 
     struct Host {
         std::vector<uint32_t> offsets;
-        std::vector<int32_t> ids;
+        std::vector<int64_t> ids;             // widened on the host so that one unpack serves both id types
         std::vector<float> data;
     };
     Host to_host(void* stream = nullptr) const {
         Host h;
         h.offsets = offsets.to_host<uint32_t>(na * nb + 1, stream);
-        h.ids = ids.to_host<int32_t>(total, stream);
+        if (id_bits == 64) {
+            h.ids = ids.to_host<int64_t>(total, stream);
+        } else {
+            const std::vector<int32_t> narrow = ids.to_host<int32_t>(total, stream);
+            h.ids.assign(narrow.begin(), narrow.end());
+        }
         if (has_data) h.data = data.to_host<float>(total, stream);
         return h;
     }
@@ -205,10 +238,14 @@ class Elements {
     static SDR_t unpack(const Host& h, size_t nb, size_t i, size_t j) {
         using Elem = detail::elem_of<SDR_t>;
         using Data = detail::data_of<SDR_t>;
+        using Id = detail::id_of<SDR_t>;
         SDR_t r;
         for (uint32_t k = h.offsets[i * nb + j]; k < h.offsets[i * nb + j + 1]; ++k) {
-            if constexpr (detail::has_value<Data>::value) r.push_back(Elem(h.ids[k], Data(h.data[k])));
-            else r.push_back(Elem(h.ids[k]));
+            if constexpr (detail::has_value<Data>::value) {
+                r.push_back(h.data.empty() ? Elem(static_cast<Id>(h.ids[k])) : Elem(static_cast<Id>(h.ids[k]), Data(h.data[k])));
+            } else {
+                r.push_back(Elem(static_cast<Id>(h.ids[k])));
+            }
         }
         return r;
     }
@@ -216,33 +253,41 @@ class Elements {
 
 class SDRBatch {
  public:
-    SDRBatch(int device, int32_t width, int data_kind) : device_(device), unit_(data_kind == SDRB_DATA_UNIT) {
-        check(sdrb_batch_create(device, width, data_kind, &h_));
+    SDRBatch(int device, int32_t width, int data_kind, int id_bits = 32)
+        : device_(device), kind_(data_kind), id_bits_(id_bits) {
+        if (id_bits == 64) check(sdrb_batch_create64(device, data_kind, &h_));
+        else check(sdrb_batch_create(device, width, data_kind, &h_));
     }
     SDRBatch(const SDRBatch&) = delete;
     SDRBatch& operator=(const SDRBatch&) = delete;
-    SDRBatch(SDRBatch&& o) noexcept : h_(o.h_), device_(o.device_), n_rows_(o.n_rows_), unit_(o.unit_) { o.h_ = nullptr; }
+    SDRBatch(SDRBatch&& o) noexcept
+        : h_(o.h_), device_(o.device_), n_rows_(o.n_rows_), kind_(o.kind_), id_bits_(o.id_bits_) { o.h_ = nullptr; }
     ~SDRBatch() { sdrb_batch_destroy(h_); }
 
     // Packs the SDRs of [first, last) by iterating each one (the portable way to read any
     // container, IDContiguousContainer.hpp:263-303 included).  width = 0: arbitrary ids.
+    // Elements with ids wider than 32 bits (SDRElem<long, ...>) make a batch of 64-bit ids.
     template <typename Iter>
     static SDRBatch pack(Iter first, Iter last, int device = 0, int32_t width = 0, void* stream = nullptr) {
         using SDR_t = std::decay_t<decltype(*first)>;
         using Data = detail::data_of<SDR_t>;
-        constexpr bool unit = detail::has_value<Data>::value;
+        constexpr bool payload = detail::has_value<Data>::value;
+        constexpr bool wide = detail::wide_ids<SDR_t>;
         std::vector<uint64_t> off{0};
-        std::vector<int32_t> ids;
+        std::vector<std::conditional_t<wide, int64_t, int32_t>> ids;
         std::vector<float> data;
         for (; first != last; ++first) {
             for (auto it = first->cbegin(); it != first->cend(); ++it) {
-                ids.push_back(static_cast<int32_t>(it->id()));
-                if constexpr (unit) data.push_back(static_cast<float>(it->data().value()));
+                ids.push_back(it->id());
+                if constexpr (payload) data.push_back(static_cast<float>(it->data().value()));
             }
             off.push_back(ids.size());
         }
-        SDRBatch b(device, width, unit ? SDRB_DATA_UNIT : SDRB_DATA_EMPTY);
-        b.upload(off, ids, data, stream);
+        SDRBatch b(device, width, detail::kind_of<Data>(), wide ? 64 : 32);
+        const float* d = data.empty() ? nullptr : data.data();
+        if constexpr (wide) check(sdrb_batch_upload_csr64(b.h_, off.size() - 1, off.data(), ids.data(), d, stream));
+        else check(sdrb_batch_upload_csr(b.h_, off.size() - 1, off.data(), ids.data(), d, stream));
+        b.n_rows_ = off.size() - 1;
         return b;
     }
 
@@ -269,6 +314,8 @@ class SDRBatch {
 
     size_t size() const { return n_rows_; }
     int device() const { return device_; }
+    int data_kind() const { return kind_; }
+    int id_bits() const { return id_bits_; }
     const sdrb_batch* handle() const { return h_; }
 
     // out(i, j) = (*this)[i].ands(db[j]) ... (SDR.hpp:175-176,229-230,257-258,317-318)
@@ -276,6 +323,15 @@ class SDRBatch {
     Counts ors(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_OR, db, flags, stream); }
     Counts xors(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_XOR, db, flags, stream); }
     Counts rms(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_RM, db, flags, stream); }
+
+    // out(i, j) = (*this)[i].inner(db[j]) on ArithData<float> rows (SDR.hpp:1682-1692), bit for bit.
+    // These are also the entries of diff_mul (SDR.hpp:1886-1923; *this = matrix rows, db = the columns
+    // of the other matrix) and of row_major_mul_vec (SDR.hpp:1729-1750; *this = the vector, db = matrix rows).
+    Values inner(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const {
+        Values v(db.device_, n_rows_, db.n_rows_);
+        check(sdrb_inner(h_, db.h_, flags, v.device_ptr(), db.n_rows_, stream));
+        return v;
+    }
 
     // For every row i: the k rows j of db with the largest |(*this)[i] ∩ db[j]| -- the value ands returns
     // on id-only elements (SDR.hpp:1083-1095); pair (i, i + exclude_offset) is skipped when exclude_offset >= 0.
@@ -293,6 +349,86 @@ class SDRBatch {
     Elements xore(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_XOR, db, flags, stream); }
     Elements rme(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_RM, db, flags, stream); }
 
+    // Row-wise forms for two batches of equal length: result j = (*this)[j].op(arg[j]).
+    // op is SDRB_OP_AND / OR / XOR / RM; sizes come as a 1 x n table, elements as a CSR with one result per row.
+    Counts rowwise_size(int op, const SDRBatch& arg, unsigned flags = 0, void* stream = nullptr) const {
+        Counts c(arg.device_, 1, arg.n_rows_);
+        check(sdrb_size_op(h_, arg.h_, op, flags | SDRB_FLAG_ROWWISE, c.device_ptr(), arg.n_rows_, stream));
+        return c;
+    }
+    Elements rowwise_elem(int op, const SDRBatch& arg, unsigned flags = 0, void* stream = nullptr) const {
+        return elem_op(op, arg, flags | SDRB_FLAG_ROWWISE, stream);
+    }
+
+    // In-place forms: every row j becomes row.andi(arg[j]) ... (SDR.hpp:1027-1081,1239-1292,1366-1422,
+    // 1436-1513).  `arg` may be *this (a.op(a) is legal in the reference, src/test.cpp:241-272).
+    SDRBatch& andi(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_AND, arg, stream); }
+    SDRBatch& ori(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_OR, arg, stream); }
+    SDRBatch& xori(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_XOR, arg, stream); }
+    SDRBatch& rmi(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_RM, arg, stream); }
+
+    // Range queries: out(r, j) = (*this)[j].ands(lo[r], hi[r]), the ids of row j in [lo, hi) (SDR.hpp:931-956),
+    // and the elements themselves, (*this)[j].ande(lo[r], hi[r]) (SDR.hpp:881-929), as a CSR over (r, j).
+    Counts range_size(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, void* stream = nullptr) const {
+        if (lo.size() != hi.size()) throw Error(SDRB_ERR_INVALID_ARG, "lo and hi differ in length");
+        Counts c(device_, lo.size(), n_rows_);
+        check(sdrb_range_size(h_, lo.size(), lo.data(), hi.data(), c.device_ptr(), n_rows_, stream));
+        return c;
+    }
+    Elements range_elems(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, void* stream = nullptr) const {
+        if (lo.size() != hi.size()) throw Error(SDRB_ERR_INVALID_ARG, "lo and hi differ in length");
+        Elements e;
+        e.na = lo.size();
+        e.nb = n_rows_;
+        e.has_data = kind_ != SDRB_DATA_EMPTY;
+        e.offsets = detail::DeviceBuffer(device_, (e.na * e.nb + 1) * sizeof(uint32_t));
+        check(sdrb_range_elems_count(h_, lo.size(), lo.data(), hi.data(), static_cast<uint32_t*>(e.offsets.ptr), &e.total, stream));
+        e.ids = detail::DeviceBuffer(device_, (e.total ? e.total : 1) * sizeof(int32_t));
+        if (e.has_data) e.data = detail::DeviceBuffer(device_, (e.total ? e.total : 1) * sizeof(float));
+        check(sdrb_range_elems_fill(h_, lo.size(), lo.data(), hi.data(), static_cast<const uint32_t*>(e.offsets.ptr),
+                                    static_cast<int32_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
+        return e;
+    }
+    // Point queries: out(q, j) = position of ids[q] in row j or -1, the batched ande(id) (SDR.hpp:860-879).
+    Positions point_query(const std::vector<int32_t>& ids, void* stream = nullptr) const {
+        Positions p(device_, ids.size(), n_rows_);
+        check(sdrb_point_query(h_, ids.size(), ids.data(), p.device_ptr(), n_rows_, stream));
+        return p;
+    }
+
+    // The batch regrouped by id: row c of the result lists the rows of *this that contain id c, ascending,
+    // with their payloads -- SDR::transpose (SDR.hpp:1807-1826) for a matrix stored as the rows of a batch.
+    SDRBatch transpose(void* stream = nullptr) const {
+        SDRBatch t(device_, 0, kind_);
+        check(sdrb_batch_transpose(h_, t.h_, stream));
+        uint64_t rows = 0;
+        check(sdrb_batch_info(t.h_, nullptr, &rows, nullptr, nullptr, nullptr, nullptr));
+        t.n_rows_ = rows;
+        return t;
+    }
+
+    // The packed rows back on the host (batches of 32-bit ids), e.g. to rebuild SDR objects after an in-place op.
+    Elements::Host to_host(void* stream = nullptr) const {
+        if (id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "to_host serves batches of 32-bit ids");
+        const uint32_t* off = nullptr;
+        const int32_t* ids = nullptr;
+        const float* data = nullptr;
+        uint64_t nnz = 0;
+        check(sdrb_batch_device_ptrs(h_, &off, &ids, &data));
+        check(sdrb_batch_info(h_, nullptr, nullptr, &nnz, nullptr, nullptr, nullptr));
+        Elements::Host h;
+        h.offsets.resize(n_rows_ + 1);
+        check(sdrb_memcpy_d2h(device_, h.offsets.data(), off, h.offsets.size() * sizeof(uint32_t), stream));
+        std::vector<int32_t> narrow(nnz);
+        if (nnz) check(sdrb_memcpy_d2h(device_, narrow.data(), ids, nnz * sizeof(int32_t), stream));
+        h.ids.assign(narrow.begin(), narrow.end());
+        if (kind_ != SDRB_DATA_EMPTY && nnz) {
+            h.data.resize(nnz);
+            check(sdrb_memcpy_d2h(device_, h.data.data(), data, nnz * sizeof(float), stream));
+        }
+        return h;
+    }
+
  private:
     Counts size_op(int op, const SDRBatch& db, unsigned flags, void* stream) const {
         Counts c(db.device_, n_rows_, db.n_rows_);
@@ -300,23 +436,41 @@ class SDRBatch {
         return c;
     }
     Elements elem_op(int op, const SDRBatch& db, unsigned flags, void* stream) const {
+        const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+        const SDRBatch& self = (flags & SDRB_FLAG_SWAP) ? db : *this;
         Elements e;
-        e.na = n_rows_;
+        e.na = rowwise ? 1 : n_rows_;
         e.nb = db.n_rows_;
-        e.has_data = (flags & SDRB_FLAG_SWAP) ? db.unit_ : unit_;
+        e.has_data = self.kind_ != SDRB_DATA_EMPTY;
+        e.id_bits = id_bits_;
         e.offsets = detail::DeviceBuffer(db.device_, (e.na * e.nb + 1) * sizeof(uint32_t));
         check(sdrb_elem_op_count(h_, db.h_, op, flags, static_cast<uint32_t*>(e.offsets.ptr), &e.total, stream));
-        e.ids = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * sizeof(int32_t));
+        e.ids = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * (id_bits_ / 8));
         if (e.has_data) e.data = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * sizeof(float));
-        check(sdrb_elem_op_fill(h_, db.h_, op, flags, static_cast<const uint32_t*>(e.offsets.ptr),
-                                static_cast<int32_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
+        if (id_bits_ == 64) {
+            check(sdrb_elem_op_fill64(h_, db.h_, op, flags, static_cast<const uint32_t*>(e.offsets.ptr),
+                                      static_cast<int64_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
+        } else {
+            check(sdrb_elem_op_fill(h_, db.h_, op, flags, static_cast<const uint32_t*>(e.offsets.ptr),
+                                    static_cast<int32_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
+        }
         return e;
+    }
+    SDRBatch& inplace(int op, const SDRBatch& arg, void* stream) {
+        if (id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "in-place operations serve batches of 32-bit ids");
+        Elements e = rowwise_elem(op, arg, 0, stream);
+        check(sdrb_batch_upload_device_csr(h_, n_rows_, static_cast<const uint32_t*>(e.offsets.ptr),
+                                           static_cast<const int32_t*>(e.ids.ptr),
+                                           e.has_data ? static_cast<const float*>(e.data.ptr) : nullptr, stream));
+        check(sdrb_stream_sync(device_, stream));   // the result buffers are released on return
+        return *this;
     }
 
     sdrb_batch* h_ = nullptr;
     int device_ = 0;
     size_t n_rows_ = 0;
-    bool unit_ = false;
+    int kind_ = SDRB_DATA_EMPTY;
+    int id_bits_ = 32;
 };
 
 }  // namespace sdr_amd

@@ -6,7 +6,8 @@
 // in [0,1] (UnitData.hpp:15-17) -- so a row range can be uploaded straight from the mapping.
 //
 //   byte 0   char     magic[8] = "SDRBCSR1"
-//        8   uint32   version (1)           12  uint32  flags (bit 0: float payloads present)
+//        8   uint32   version (1)           12  uint32  flags (bit 0: float payloads present;
+//                                                                  bit 1: they are ArithData, else UnitData)
 //       16   uint32   id_bits (32)          20  int32   width (0 = undeclared)
 //       24   uint64   n_rows                32  uint64  nnz
 //       40   uint64   ids_pos               48  uint64  data_pos (0 = none)      56  uint64  offsets_pos
@@ -150,7 +151,8 @@ struct sdrb_file_writer {
     int data_fd = -1;            // payloads are streamed to a sidecar and appended on close
     std::string path, data_path;
     int32_t width = 0;
-    bool unit = false;
+    bool unit = false;           // a float payload per element (UnitData or ArithData)
+    bool arith = false;          // ... of ArithData: any finite value instead of [0,1]
     uint64_t pos = 0;            // write position in the main file
     uint64_t nnz = 0;
     std::vector<uint64_t> offsets{0};
@@ -159,14 +161,15 @@ struct sdrb_file_writer {
 extern "C" {
 
 int sdrb_file_writer_open(const char* path, int32_t width, int data_kind, sdrb_file_writer** out) {
-    if (!path || !out || width < 0 || (data_kind != SDRB_DATA_EMPTY && data_kind != SDRB_DATA_UNIT)) {
+    if (!path || !out || width < 0 || (data_kind != SDRB_DATA_EMPTY && data_kind != SDRB_DATA_UNIT && data_kind != SDRB_DATA_ARITH)) {
         set_error("sdrb_file_writer_open: bad argument");
         return SDRB_ERR_INVALID_ARG;
     }
     sdrb_file_writer* w = new sdrb_file_writer;
     w->path = path;
     w->width = width;
-    w->unit = data_kind == SDRB_DATA_UNIT;
+    w->unit = data_kind != SDRB_DATA_EMPTY;
+    w->arith = data_kind == SDRB_DATA_ARITH;
     w->fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (w->fd < 0) {
         set_error("cannot create %s: %s", path, std::strerror(errno));
@@ -221,8 +224,12 @@ int sdrb_file_writer_append(sdrb_file_writer* w, uint64_t n_rows, const uint64_t
                 set_error("id %d outside the declared width %d", ids[k], w->width);
                 return SDRB_ERR_ID_RANGE;
             }
-            if (w->unit && !(data[k] >= 0.0f && data[k] <= 1.0f)) {
+            if (w->unit && !w->arith && !(data[k] >= 0.0f && data[k] <= 1.0f)) {
                 set_error("UnitData payload %g is outside [0,1]", (double)data[k]);
+                return SDRB_ERR_PAYLOAD_RANGE;
+            }
+            if (w->arith && !(data[k] - data[k] == 0.0f)) {
+                set_error("ArithData payload of row %llu of the chunk is not finite", (unsigned long long)r);
                 return SDRB_ERR_PAYLOAD_RANGE;
             }
         }
@@ -243,7 +250,7 @@ int sdrb_file_writer_close(sdrb_file_writer* w) {
     Header h{};
     std::memcpy(h.magic, kMagic, 8);
     h.version = 1;
-    h.flags = w->unit ? 1u : 0u;
+    h.flags = (w->unit ? 1u : 0u) | (w->arith ? 2u : 0u);
     h.id_bits = 32;
     h.width = w->width;
     h.n_rows = w->offsets.size() - 1;
@@ -308,7 +315,7 @@ int sdrb_file_info(const char* path, uint64_t* n_rows, uint64_t* nnz, int32_t* w
     if (n_rows) *n_rows = m.h->n_rows;
     if (nnz) *nnz = m.h->nnz;
     if (width) *width = m.h->width;
-    if (data_kind) *data_kind = (m.h->flags & 1u) ? SDRB_DATA_UNIT : SDRB_DATA_EMPTY;
+    if (data_kind) *data_kind = !(m.h->flags & 1u) ? SDRB_DATA_EMPTY : (m.h->flags & 2u) ? SDRB_DATA_ARITH : SDRB_DATA_UNIT;
     return SDRB_OK;
 }
 
@@ -356,9 +363,13 @@ int sdrb_batch_upload_file(sdrb_batch* batch, const char* path, uint64_t row_lo,
     if (rc != SDRB_OK) return rc;
     rc = check_range(m, row_lo, row_hi);
     if (rc != SDRB_OK) return rc;
-    const bool file_unit = (m.h->flags & 1u) != 0;
-    if ((batch->data_kind == SDRB_DATA_UNIT) && !file_unit) {
-        set_error("%s holds no payloads but the batch is UnitData", path);
+    const bool file_data = (m.h->flags & 1u) != 0, file_arith = (m.h->flags & 2u) != 0;
+    if (sdrb::has_payload(batch) && !file_data) {
+        set_error("%s holds no payloads but the batch has them", path);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (batch->data_kind == SDRB_DATA_UNIT && file_arith) {
+        set_error("%s holds ArithData payloads but the batch is UnitData", path);
         return SDRB_ERR_INVALID_ARG;
     }
     // rows are uploaded straight from the mapping; only the rebased offsets are materialised
@@ -366,7 +377,7 @@ int sdrb_batch_upload_file(sdrb_batch* batch, const char* path, uint64_t row_lo,
     std::vector<uint64_t> off(row_hi - row_lo + 1);
     for (uint64_t r = row_lo; r <= row_hi; ++r) off[r - row_lo] = m.offsets[r] - e0;
     return sdrb_batch_upload_csr(batch, row_hi - row_lo, off.data(), m.ids + e0,
-                                 batch->data_kind == SDRB_DATA_UNIT ? m.data + e0 : nullptr, stream);
+                                 sdrb::has_payload(batch) ? m.data + e0 : nullptr, stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from ._lib import DATA_EMPTY, DATA_UNIT, check, load
+from ._lib import DATA_ARITH, DATA_EMPTY, DATA_UNIT, check, load
 
 
 def _path(p) -> bytes:
@@ -28,12 +28,15 @@ class Writer:
                 w.append(off, ids, data)
     """
 
-    def __init__(self, path, *, width: int = 0, payloads: bool = False):
+    def __init__(self, path, *, width: int = 0, payloads: bool = False, kind: Optional[str] = None):
+        """``kind``: "empty", "unit" (payloads in [0,1]) or "arith" (any finite float); by default
+        "unit" when ``payloads`` is set, else "empty"."""
         self._lib = load()
         self._h = C.c_void_p()
-        self.payloads = payloads
-        check(self._lib.sdrb_file_writer_open(_path(path), width, DATA_UNIT if payloads else DATA_EMPTY,
-                                              C.byref(self._h)))
+        code = {None: DATA_UNIT if payloads else DATA_EMPTY, "empty": DATA_EMPTY, "unit": DATA_UNIT,
+                "arith": DATA_ARITH}[kind]
+        self.payloads = code != DATA_EMPTY
+        check(self._lib.sdrb_file_writer_open(_path(path), width, code, C.byref(self._h)))
 
     def append(self, offsets, ids, data=None) -> None:
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -69,9 +72,9 @@ class Writer:
         return False
 
 
-def write(path, offsets, ids, data=None, *, width: int = 0) -> None:
+def write(path, offsets, ids, data=None, *, width: int = 0, kind: Optional[str] = None) -> None:
     """Writes a whole host CSR as one file."""
-    with Writer(path, width=width, payloads=data is not None) as w:
+    with Writer(path, width=width, payloads=data is not None, kind=kind) as w:
         w.append(offsets, ids, data)
 
 
@@ -80,7 +83,8 @@ def info(path) -> dict:
     n_rows, nnz, width, kind = C.c_uint64(), C.c_uint64(), C.c_int32(), C.c_int()
     check(lib.sdrb_file_info(_path(path), C.byref(n_rows), C.byref(nnz), C.byref(width), C.byref(kind)))
     return dict(n_rows=int(n_rows.value), nnz=int(nnz.value), width=int(width.value),
-                payloads=kind.value == DATA_UNIT)
+                payloads=kind.value != DATA_EMPTY,
+                kind={DATA_EMPTY: "empty", DATA_UNIT: "unit", DATA_ARITH: "arith"}[kind.value])
 
 
 def read_rows(path, row_lo: int = 0, row_hi: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
@@ -102,13 +106,14 @@ def read_rows(path, row_lo: int = 0, row_hi: Optional[int] = None) -> Tuple[np.n
 def upload_rows(path, row_lo: int = 0, row_hi: Optional[int] = None, *, device: int = 0, payloads: Optional[bool] = None,
                 stream=None):
     """Packs rows ``[row_lo, row_hi)`` of a file into a new device batch (e.g. one rank's shard of a
-    database file).  ``payloads=False`` drops the payloads of a UnitData file."""
+    database file).  ``payloads=False`` drops the payloads of the file."""
     from .batch import SDRBatch, _stream_handle
     meta = info(path)
     if row_hi is None:
         row_hi = meta["n_rows"]
     use_payloads = meta["payloads"] if payloads is None else payloads
-    b = SDRBatch(device, meta["width"], DATA_UNIT if use_payloads else DATA_EMPTY)
+    code = DATA_EMPTY if not use_payloads else DATA_ARITH if meta["kind"] == "arith" else DATA_UNIT
+    b = SDRBatch(device, meta["width"], code)
     check(b._lib.sdrb_batch_upload_file(b._h, _path(path), row_lo, row_hi, _stream_handle(device, stream)))
     b._refresh_info()
     return b

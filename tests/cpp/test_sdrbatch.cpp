@@ -5,6 +5,7 @@
 // oracle/_ref/test_sdrbatch); the GPU test-suite runs the binary when it is present.
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <forward_list>
 #include <random>
 #include <set>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "SparseDistributedRepresentation/SDR.hpp"
+#include "SparseDistributedRepresentation/DataTypes/ArithData.hpp"
 #include "SparseDistributedRepresentation/DataTypes/UnitData.hpp"
 #include "SparseDistributedRepresentation/IDContiguousContainer.hpp"
 #include "sdr_amd/SDRBatch.hpp"
@@ -26,14 +28,19 @@ std::vector<SDR_t> make_rows(std::mt19937& rng, size_t n, int width, int max_len
     using Elem = typename SDR_t::value_type;
     using Data = typename Elem::data_type;
     std::vector<SDR_t> rows(n);
+    using Id = typename Elem::id_type;
     std::uniform_real_distribution<float> val(0.0f, 1.0f);
+    std::normal_distribution<float> gauss(0.0f, 3.0f);
     for (auto& r : rows) {
         int len = (int)(rng() % (unsigned)(max_len + 1));
         std::set<int> ids;
         while ((int)ids.size() < len) ids.insert((int)(rng() % (unsigned)width));
         std::vector<Elem> elems;
-        for (int id : ids) {
+        for (int small : ids) {
+            Id id = small;
+            if constexpr (sizeof(Id) > 4) id = (Id)small * 0x100000003L - 0x4000000000L;   // ids that need 64 bits, order kept
             if constexpr (std::is_same_v<Data, UnitData>) elems.push_back(Elem(id, UnitData(val(rng))));
+            else if constexpr (std::is_same_v<Data, ArithData<float>>) elems.push_back(Elem(id, ArithData<float>(gauss(rng))));
             else elems.push_back(Elem(id));
         }
         if constexpr (SDR_t::uses_flist_like) {
@@ -96,6 +103,146 @@ int run_allpairs(std::mt19937& rng, unsigned flags, const char* name) {
     return 0;
 }
 
+// sparse dot products on ArithData<float> rows: every entry equals the reference's inner() bit for bit,
+// and so do the entries of row_major_mul_vec (one vector against the rows of a matrix)
+template <typename B>
+int run_inner(std::mt19937& rng, const char* name) {
+    using AE = SDRElem<int, ArithData<float>>;
+    auto qs = make_rows<SDR<AE>>(rng, 23, 256, 40);
+    auto ds = make_rows<B>(rng, 211, 256, 40);
+    auto q = sdr_amd::SDRBatch::pack(qs.begin(), qs.end(), 0, 256);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 256);
+    REQUIRE(q.data_kind() == SDRB_DATA_ARITH);
+    auto v = q.inner(d).to_host();
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            const float want = qs[i].template inner<ArithData<float>>(ds[j]).value();
+            REQUIRE(std::memcmp(&v[i * ds.size() + j], &want, 4) == 0);
+        }
+    if constexpr (std::is_same_v<typename B::value_type, AE>) {
+        // matrix (rows ds, row ids 0..n-1) times vector qs[0]: row_major_mul_vec keeps every row (ArithData is always relevant)
+        using Row = SDRElem<int, SDR<AE>>;
+        SDR<Row> m;
+        for (size_t j = 0; j < ds.size(); ++j) m.push_back(Row((int)j, SDR<AE>(ds[j])));
+        auto prod = m.row_major_mul_vec(qs[0]);
+        auto d_as_this = d.inner(q).to_host();   // d_j.inner(q_i) at [j][i]
+        size_t j = 0;
+        for (auto it = prod.cbegin(); it != prod.cend(); ++it, ++j) {
+            REQUIRE((size_t)it->id() == j);
+            const float want = it->data().value();
+            REQUIRE(std::memcmp(&d_as_this[j * qs.size() + 0], &want, 4) == 0);
+        }
+        REQUIRE(j == ds.size());
+    }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
+// row-wise and in-place forms: b.andi(c) ... on whole batches equal the reference's in-place results, a.op(a) included
+template <typename A, typename B>
+int run_inplace(std::mt19937& rng, const char* name) {
+    using R = SDR<typename A::value_type, std::vector<typename A::value_type>>;
+    const int ops[4] = {SDRB_OP_AND, SDRB_OP_OR, SDRB_OP_XOR, SDRB_OP_RM};
+    for (int op : ops) {
+        auto as = make_rows<A>(rng, 150, 128, 40);
+        auto bs = make_rows<B>(rng, 150, 128, 40);
+        auto a = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 128);
+        auto b = sdr_amd::SDRBatch::pack(bs.begin(), bs.end(), 0, 128);
+        auto sizes = a.rowwise_size(op, b).to_host();
+        switch (op) {
+            case SDRB_OP_AND: a.andi(b); break;
+            case SDRB_OP_OR: a.ori(b); break;
+            case SDRB_OP_XOR: a.xori(b); break;
+            default: a.rmi(b); break;
+        }
+        auto h = a.to_host();
+        for (size_t j = 0; j < as.size(); ++j) {
+            size_t want_size = op == SDRB_OP_AND ? as[j].ands(bs[j]) : op == SDRB_OP_OR ? as[j].ors(bs[j])
+                             : op == SDRB_OP_XOR ? as[j].xors(bs[j]) : as[j].rms(bs[j]);
+            REQUIRE(sizes[j] == want_size);
+            R want(as[j].cbegin(), as[j].cend());
+            switch (op) {
+                case SDRB_OP_AND: want.andi(bs[j]); break;
+                case SDRB_OP_OR: want.ori(bs[j]); break;
+                case SDRB_OP_XOR: want.xori(bs[j]); break;
+                default: want.rmi(bs[j]); break;
+            }
+            REQUIRE(sdr_amd::Elements::unpack<R>(h, as.size(), 0, j) == want);
+        }
+    }
+    // a.op(a) (src/test.cpp:241-272)
+    auto as = make_rows<A>(rng, 60, 128, 40);
+    for (int op : ops) {
+        auto a = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 128);
+        switch (op) {
+            case SDRB_OP_AND: a.andi(a); break;
+            case SDRB_OP_OR: a.ori(a); break;
+            case SDRB_OP_XOR: a.xori(a); break;
+            default: a.rmi(a); break;
+        }
+        auto h = a.to_host();
+        for (size_t j = 0; j < as.size(); ++j) {
+            R want(as[j].cbegin(), as[j].cend());
+            switch (op) {
+                case SDRB_OP_AND: want.andi(want); break;
+                case SDRB_OP_OR: want.ori(want); break;
+                case SDRB_OP_XOR: want.xori(want); break;
+                default: want.rmi(want); break;
+            }
+            REQUIRE(sdr_amd::Elements::unpack<R>(h, as.size(), 0, j) == want);
+        }
+    }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
+// range / point queries and the transpose against the reference's members
+int run_queries(std::mt19937& rng, const char* name) {
+    using U = SDRElem<int, UnitData>;
+    using R = SDR<U>;
+    auto ds = make_rows<R>(rng, 180, 300, 40);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 300);
+    const std::vector<int32_t> lo{0, 10, 150, 299, 77, 0}, hi{300, 20, 150, 300, 260, 1};
+    auto sizes = d.range_size(lo, hi).to_host();
+    auto elems = d.range_elems(lo, hi).to_host();
+    for (size_t r = 0; r < lo.size(); ++r)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            REQUIRE(sizes[r * ds.size() + j] == ds[j].ands(lo[r], hi[r]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(elems, ds.size(), r, j) == ds[j].ande(lo[r], hi[r]));
+        }
+    const std::vector<int32_t> probe{0, 5, 123, 299, 300, -4};
+    auto pos = d.point_query(probe).to_host();
+    auto host = d.to_host();
+    for (size_t q = 0; q < probe.size(); ++q)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            const UnitData* want = ds[j].ande(probe[q]);
+            const int32_t p = pos[q * ds.size() + j];
+            REQUIRE((want != nullptr) == (p >= 0));
+            if (want) REQUIRE(host.data[host.offsets[j] + p] == want->value());
+        }
+    // transpose: row c of the result lists, ascending, exactly the rows j with ds[j].ande(c) != nullptr and
+    // carries their payloads.  (The reference's own transpose() fills columns in heap order and trips its
+    // push_back assertion in a build with asserts on, so its point lookup is the pin here; the committed
+    // fixture of the Python suite holds transpose() outputs from a build without asserts.)
+    auto t = d.transpose();
+    REQUIRE(t.size() == 300);
+    auto th = t.to_host();
+    for (int c = 0; c < 300; ++c) {
+        uint32_t k = th.offsets[c];
+        for (size_t j = 0; j < ds.size(); ++j) {
+            const UnitData* want = ds[j].ande(c);
+            if (!want) continue;
+            REQUIRE(k < th.offsets[c + 1]);
+            REQUIRE(th.ids[k] == (int64_t)j);
+            REQUIRE(th.data[k] == want->value());
+            ++k;
+        }
+        REQUIRE(k == th.offsets[c + 1]);
+    }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
 // database files: SDR objects -> file -> SDR objects (reference operator==), and a batch loaded from
 // a row range of the file gives the reference's counts
 template <typename SDR_t>
@@ -111,18 +258,29 @@ int run_file(std::mt19937& rng, const char* name) {
     for (size_t r = 0; r < part.size(); ++r) REQUIRE(part[r] == ds[100 + r]);
     auto shard = sdr_amd::SDRBatch::from_file(path, 0, 100, 400);
     auto q = sdr_amd::SDRBatch::pack(ds.begin(), ds.begin() + 20, 0, 400);
-    auto counts = q.ands(shard).to_host();
-    for (size_t i = 0; i < 20; ++i)
-        for (size_t j = 0; j < 300; ++j) REQUIRE(counts[i * 300 + j] == ds[i].ands(ds[100 + j]));
+    if constexpr (std::is_same_v<typename SDR_t::value_type::data_type, ArithData<float>>) {
+        auto dots = q.inner(shard).to_host();
+        for (size_t i = 0; i < 20; ++i)
+            for (size_t j = 0; j < 300; ++j)
+                REQUIRE(dots[i * 300 + j] == ds[i].template inner<ArithData<float>>(ds[100 + j]).value());
+    } else {
+        auto counts = q.ands(shard).to_host();
+        for (size_t i = 0; i < 20; ++i)
+            for (size_t j = 0; j < 300; ++j) REQUIRE(counts[i * 300 + j] == ds[i].ands(ds[100 + j]));
+    }
     std::remove(path.c_str());
     std::printf("ok %-28s %ld checks so far\n", name, g_checks);
     return 0;
 }
 
 int main() {
+    std::setvbuf(stdout, nullptr, _IOLBF, 0);   // progress survives an assert of the reference
     std::mt19937 rng(12345);
     using E = SDRElem<>;
     using U = SDRElem<int, UnitData>;
+    using AE = SDRElem<int, ArithData<float>>;
+    using LE = SDRElem<long>;
+    using LU = SDRElem<long, UnitData>;
     try {
         if (run<SDR<E>, SDR<E>>("vec x vec (table kernel)", rng, 512, 512)) return 1;
         if (run<SDR<E>, SDR<E>>("vec x vec (merge kernel)", rng, 512, 0)) return 1;
@@ -131,8 +289,18 @@ int main() {
         if (run<SDR<U>, SDR<E>>("unit x empty", rng, 200, 200)) return 1;
         if (run<SDR<E>, SDR<U>>("empty x unit", rng, 200, 200)) return 1;
         if (run<SDR<U, IDContiguousContainer<U>>, SDR<U, IDContiguousContainer<U>>>("idcontiguous x idcontiguous", rng, 200, 0)) return 1;
+        if (run<SDR<LE>, SDR<LE>>("long ids", rng, 512, 0)) return 1;
+        if (run<SDR<LU>, SDR<LU>>("long ids, unit x unit", rng, 200, 0)) return 1;
+        if (run<SDR<LU>, SDR<LE>>("long ids, unit x empty", rng, 200, 0)) return 1;
+        if (run_inner<SDR<AE>>(rng, "inner arith x arith")) return 1;
+        if (run_inner<SDR<E>>(rng, "inner arith x empty")) return 1;
+        if (run_inplace<SDR<E>, SDR<E>>(rng, "in-place empty x empty")) return 1;
+        if (run_inplace<SDR<U>, SDR<U>>(rng, "in-place unit x unit")) return 1;
+        if (run_inplace<SDR<U>, SDR<E>>(rng, "in-place unit x empty")) return 1;
+        if (run_queries(rng, "range/point/transpose")) return 1;
         if (run_file<SDR<E>>(rng, "file_empty")) return 1;
         if (run_file<SDR<U>>(rng, "file_unit")) return 1;
+        if (run_file<SDR<AE>>(rng, "file_arith")) return 1;
         if (run_allpairs(rng, 0, "all-pairs top-k (default)")) return 1;
         if (run_allpairs(rng, SDRB_FLAG_FORCE_MFMA, "all-pairs top-k (matrix cores)")) return 1;
     } catch (const sdr_amd::Error& e) {

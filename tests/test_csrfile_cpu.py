@@ -28,7 +28,8 @@ def test_streamed_chunks_round_trip(tmp_path, payloads):
             w.append(off[lo:hi + 1] - off[lo], ids[e0:e1], None if data is None else data[e0:e1])
     assert not os.path.exists(str(path) + ".payload.tmp")
     meta = csrfile.info(path)
-    assert meta == dict(n_rows=1000, nnz=int(off[-1]), width=2048, payloads=payloads)
+    assert meta == dict(n_rows=1000, nnz=int(off[-1]), width=2048, payloads=payloads,
+                        kind="unit" if payloads else "empty")
     r_off, r_ids, r_data = csrfile.read_rows(path)
     assert np.array_equal(r_off, off) and np.array_equal(r_ids, ids)
     assert (r_data is None) == (data is None) and (data is None or np.array_equal(r_data.view(np.uint32), data.view(np.uint32)))
@@ -50,6 +51,21 @@ def test_empty_database_and_empty_rows(tmp_path):
     csrfile.write(path, np.array([0, 0, 2, 2], np.uint64), np.array([5, 9], np.int32))
     off, ids, _ = csrfile.read_rows(path, 1, 3)
     assert off.tolist() == [0, 2, 2] and ids.tolist() == [5, 9]
+
+
+def test_arith_payloads(tmp_path):
+    """ArithData<float> rows: any finite value is stored, bit for bit; non-finite ones are refused."""
+    rng = np.random.default_rng(7)
+    off, ids, _ = util.ragged_rows(rng, 200, 512, 30, False)
+    data = (rng.standard_normal(ids.size) * 1e3).astype(np.float32)
+    path = tmp_path / "arith.sdrb"
+    csrfile.write(path, off, ids, data, width=512, kind="arith")
+    assert csrfile.info(path)["kind"] == "arith" and csrfile.info(path)["payloads"]
+    _, r_ids, r_data = csrfile.read_rows(path)
+    assert np.array_equal(r_ids, ids) and np.array_equal(r_data.view(np.uint32), data.view(np.uint32))
+    with pytest.raises(SdrbError) as e:
+        csrfile.write(path, np.array([0, 1], np.uint64), np.array([1], np.int32), np.array([np.inf], np.float32), kind="arith")
+    assert e.value.code == -7
 
 
 def test_writer_rejects_what_an_upload_rejects(tmp_path):
