@@ -917,6 +917,13 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & SDRB_FLAG_FORCE_RANK) {
+        if (rowwise || !elem_rank_applicable(a, b)) {
+            set_error("the rank-table fill needs all-pairs evaluation, 32-bit ids and a declared width <= 32768 that holds every id");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_elem_rank(a, b, op, swap, out_offsets, out_ids, out_data, s);
+    }
     if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32) {
         // intersections are small: visiting only the matches (mask table) beats enumerating whole bitsets
         if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && mask_table_applicable(a, b))
@@ -924,6 +931,7 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
         if (unit_table_fill_applicable(a, b, op, swap))
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
+        if (elem_rank_applicable(a, b)) return launch_elem_rank(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }
     return launch_elem_fill(a, b, op, swap, out_offsets, out_ids_any, out_data, rowwise, s);
 }

@@ -1,0 +1,400 @@
+// Element operations with one WAVE per pair, for results that carry payloads or rows too wide for
+// the dense-bitset kernel: every output position is computed from ranks, so the 64 lanes of a wave
+// write a pair's result together instead of one lane walking the merge.
+//
+// A sorted duplicate-free row over a declared width W is a W-bit set; with the exclusive popcount
+// prefix of its 32-bit words stored beside them, rank(x) = #{ids < x} costs one 64-bit table read and
+// a popcount, and for an id that is present rank(x) is its position in the row, i.e. where its payload
+// lives.  Each wave builds this table for its row of B in LDS; the tables of all rows of A are built
+// once per call in global memory and staged in LDS by the blocks that use them.
+//
+// Per pair (this = T, arg = G; SDRB_FLAG_SWAP decides which of A_i / B_j is T) the lanes walk T in
+// id order, 64 elements per turn, look each id up in G and decide what the reference's merge decides:
+//   this-only -> copied (not for ande)                         SDR.hpp:1207-1209,1332-1334,1541-1543
+//   match     -> payload op, kept as the op says               SDR.hpp:1015-1021,1213-1217,1338-1344,1544-1548
+// For ande / rme nothing else is emitted, so the output position of an element is the number of
+// emitted elements before it: a ballot prefix.  For ore / xore the arg-only elements interleave, so
+//   pos(t)          = #emitted T elements before t  +  rank_G(t) - #matches before t
+//   pos(g, G-only)  = rank_T(g) - #dropped matches before g  +  #G-only elements before g
+// and a second walk over G emits the converted arg-only elements (SDR.hpp:1210-1212,1335-1337;
+// an EmptyData argument becomes UnitData 1.0, UnitData.hpp:13-14).  "Dropped" is evaluated with the
+// same single-rounding payload operation on both walks, so the two agree.
+#include "sdrb_device.h"
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+using u64 = unsigned long long;
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kQueryChunk = 16;   // rows of A a wave visits per row of B (grid.y splits A)
+
+template <typename T>
+__device__ __forceinline__ void lds_store(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <typename T>
+__device__ __forceinline__ T lds_load(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// lanes below mine whose flag is set, and the wave's total
+__device__ __forceinline__ uint32_t prefix_of(bool flag, uint32_t& total) {
+    const u64 m = __builtin_amdgcn_ballot_w64(flag);
+    total = (uint32_t)__builtin_popcountll(m);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Rank table of a row: entry w = {bits of ids 32w .. 32w+31, number of ids below 32w}, so that one
+// 64-bit read serves a lookup.
+struct alignas(8) RankEntry {
+    uint32_t bits;
+    uint32_t below;
+};
+
+// rank of id x in a row with table `tab` (LDS); `present` says whether x is in the row
+__device__ __forceinline__ uint32_t rank_in(const RankEntry* tab, uint32_t x, bool& present) {
+    const u64 raw = lds_load(reinterpret_cast<const u64*>(tab + (x >> 5)));
+    const uint32_t bits = (uint32_t)raw, below = (uint32_t)(raw >> 32);
+    const uint32_t sh = x & 31;
+    present = (bits >> sh) & 1;
+    return below + (uint32_t)__builtin_popcount(bits & ((1u << sh) - 1u));
+}
+
+// Rank tables of every row of A (one block per row; nw 32-bit words per row).
+__global__ __launch_bounds__(kBlock) void k_build_rank_tables(const uint32_t* __restrict__ a_off,
+                                                              const int32_t* __restrict__ a_ids, uint32_t nw,
+                                                              RankEntry* __restrict__ tab) {
+    extern __shared__ uint32_t s_bits[];
+    __shared__ uint32_t s_wave_tot[kWaves];
+    const uint64_t i = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t w = threadIdx.x; w < nw; w += kBlock) s_bits[w] = 0;
+    __syncthreads();
+    const uint32_t beg = a_off[i], len = a_off[i + 1] - beg;
+    for (uint32_t k = threadIdx.x; k < len; k += kBlock) {
+        const uint32_t id = (uint32_t)a_ids[beg + k];   // host checked 0 <= id < 32 * nw
+        atomicOr(&s_bits[id >> 5], 1u << (id & 31));
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w0 = 0; w0 < nw; w0 += kBlock) {
+        const uint32_t w = w0 + threadIdx.x;
+        const uint32_t word = w < nw ? s_bits[w] : 0u;
+        const uint32_t c = (uint32_t)__builtin_popcount(word);
+        const uint32_t incl = wave_inclusive_scan(c);
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < kWaves; ++v) {
+            if (v < (int)wave) wave_base += s_wave_tot[v];
+            total += s_wave_tot[v];
+        }
+        if (w < nw) tab[i * nw + w] = RankEntry{word, base + wave_base + incl - c};
+        base += total;
+        __syncthreads();
+    }
+}
+
+// What bounds a wave here is waiting, not arithmetic: on this hardware a wait for a load also waits
+// for every store issued before it, so a pair must not touch global memory except to store.  The
+// block therefore stages its (at most kQueryChunk) rows of A once -- rank tables, ids and payloads --
+// in LDS; a wave stages its row of B per row, keeps the first 64 elements of it in registers, and
+// fetches the output offsets of all its pairs with one load per row of B.
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+__global__ __launch_bounds__(kBlock) void k_elem_rank(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_data,
+    uint32_t na, const RankEntry* __restrict__ a_tab, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint32_t nb,
+    const uint32_t* __restrict__ out_off, int32_t* __restrict__ out_ids, float* __restrict__ out_data,
+    uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b, uint32_t rows_per_wave) {
+    constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
+    constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
+    constexpr bool UNION = OP == SDRB_OP_OR || OP == SDRB_OP_XOR;
+    // matches of a xore can be dropped one by one only when `this` carries payloads
+    constexpr bool DROP_BY_VALUE = OP == SDRB_OP_XOR && THIS_UNIT;
+    // LDS: tables of the waves' rows of B | tables of the block's rows of A | rows of A: ids, payloads |
+    //      the waves' rows of B: ids, payloads   (cap_a / cap_b elements per row)
+    extern __shared__ RankEntry smem[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RankEntry* btab = smem + (size_t)wave * nw;
+    RankEntry* atab_all = smem + (size_t)kWaves * nw;
+    uint32_t* a_ids_all = reinterpret_cast<uint32_t*>(atab_all + (size_t)qc * nw);
+    float* a_val_all = reinterpret_cast<float*>(a_ids_all + (size_t)qc * cap_a);
+    uint32_t* b_ids_l = reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * cap_a) + (size_t)wave * cap_b;
+    float* b_val_l = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * cap_a) +
+                                              (size_t)kWaves * cap_b) + (size_t)wave * cap_b;
+
+    const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * rows_per_wave;
+    const uint64_t j_end = j_begin + rows_per_wave < nb ? j_begin + rows_per_wave : nb;
+    const uint32_t i_begin = blockIdx.y * qc;
+    const uint32_t ni = (i_begin + qc < na ? i_begin + qc : na) - i_begin;
+    // row offsets of the block's rows of A, one per lane (lanes 0..ni)
+    const int a_off_reg = (int)a_off[i_begin + (lane <= ni ? lane : ni)];
+
+    for (uint32_t idx = threadIdx.x; idx < ni * nw; idx += kBlock) atab_all[idx] = a_tab[(size_t)i_begin * nw + idx];
+    for (uint32_t ii = 0; ii < ni; ++ii) {
+        const uint32_t beg = a_off[i_begin + ii], len = a_off[i_begin + ii + 1] - beg;   // len <= cap_a (host)
+        for (uint32_t l = threadIdx.x; l < len; l += kBlock) {
+            a_ids_all[ii * cap_a + l] = (uint32_t)a_ids[beg + l];
+            a_val_all[ii * cap_a + l] = A_UNIT ? a_data[beg + l] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    for (uint64_t j = j_begin; j < j_end; ++j) {
+        const uint32_t b_beg = b_off[j], lb = b_off[j + 1] - b_beg;   // lb <= cap_b (host)
+        const int base_reg = lane < ni ? (int)out_off[(uint64_t)(i_begin + lane) * nb + j] : 0;
+        // row j of B: copy it into LDS and build its table (zero, OR the ids in, prefix the popcounts)
+        for (uint32_t w = lane; w < nw; w += 64) lds_store(reinterpret_cast<u64*>(btab + w), (u64)0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        uint32_t b_x0 = 0;
+        float b_v0 = 0.0f;
+        for (uint32_t k = lane; k < lb; k += 64) {
+            const uint32_t id = (uint32_t)b_ids[b_beg + k];
+            const float val = B_UNIT ? b_data[b_beg + k] : 0.0f;
+            if (k < 64) {
+                b_x0 = id;
+                b_v0 = val;
+            }
+            lds_store(&b_ids_l[k], id);
+            lds_store(&b_val_l[k], val);
+            __hip_atomic_fetch_or(&btab[id >> 5].bits, 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const uint32_t c = w < nw ? (uint32_t)__builtin_popcount(lds_load(&btab[w].bits)) : 0u;
+            const uint32_t incl = wave_inclusive_scan(c);
+            if (w < nw) lds_store(&btab[w].below, run + incl - c);
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        for (uint32_t ii = 0; ii < ni; ++ii) {
+            const uint32_t la = (uint32_t)(__builtin_amdgcn_readlane(a_off_reg, (int)ii + 1) -
+                                           __builtin_amdgcn_readlane(a_off_reg, (int)ii));
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane(base_reg, (int)ii);
+            const RankEntry* atab = atab_all + (size_t)ii * nw;
+            const uint32_t* a_ids_l = a_ids_all + (size_t)ii * cap_a;
+            const float* a_val_l = a_val_all + (size_t)ii * cap_a;
+            const uint32_t a_x0 = lane < la ? lds_load(&a_ids_l[lane]) : 0u;
+            const float a_v0 = (A_UNIT && lane < la) ? lds_load(&a_val_l[lane]) : 0.0f;
+
+            // `this` and `arg` views of the pair (rows and tables in LDS, first 64 elements in registers)
+            const uint32_t* t_ids = SWAP ? b_ids_l : a_ids_l;
+            const float* t_val = SWAP ? b_val_l : a_val_l;
+            const uint32_t lt = SWAP ? lb : la;
+            const uint32_t t_x0 = SWAP ? b_x0 : a_x0;
+            const float t_v0 = SWAP ? b_v0 : a_v0;
+            const RankEntry* t_tab = SWAP ? btab : atab;
+            const uint32_t* g_ids = SWAP ? a_ids_l : b_ids_l;
+            const float* g_val = SWAP ? a_val_l : b_val_l;
+            const uint32_t lg = SWAP ? la : lb;
+            const uint32_t g_x0 = SWAP ? a_x0 : b_x0;
+            const float g_v0 = SWAP ? a_v0 : b_v0;
+            const RankEntry* g_tab = SWAP ? atab : btab;
+
+            // walk `this`: this-only elements and kept matches, 64 per turn
+            uint32_t emitted = 0, matched = 0;
+            for (uint32_t k0 = 0; k0 < lt; k0 += 64) {
+                const bool live = k0 + lane < lt;
+                uint32_t x = t_x0;
+                float v = t_v0;
+                if (k0 != 0) {
+                    x = live ? lds_load(&t_ids[k0 + lane]) : 0u;
+                    v = (THIS_UNIT && live) ? lds_load(&t_val[k0 + lane]) : 0.0f;
+                }
+                bool hit = false;
+                const uint32_t rg = rank_in(g_tab, x, hit);
+                hit = hit && live;
+                bool keep = live && OP != SDRB_OP_AND;
+                if (hit) {
+                    const float gv = ARG_UNIT ? lds_load(&g_val[rg]) : 0.0f;   // a present id's rank is its position
+                    v = match_data<OP, ARG_UNIT>(v, gv);
+                    keep = match_kept<OP, THIS_UNIT>(v);
+                }
+                uint32_t n_keep, n_hit = 0;
+                uint32_t pos = emitted + prefix_of(keep, n_keep);
+                if constexpr (UNION) {
+                    pos += rg - (matched + prefix_of(hit, n_hit));   // arg-only elements below x
+                }
+                if (keep) {
+                    out_ids[base + pos] = (int32_t)x;
+                    if constexpr (THIS_UNIT) out_data[base + pos] = v;
+                }
+                emitted += n_keep;
+                matched += n_hit;
+            }
+            if constexpr (UNION) {
+                // walk `arg`: its unmatched elements, converted to the result's element type
+                uint32_t singles = 0, dropped = 0;
+                for (uint32_t k0 = 0; k0 < lg; k0 += 64) {
+                    const bool live = k0 + lane < lg;
+                    uint32_t x = g_x0;
+                    float v = g_v0;
+                    if (k0 != 0) {
+                        x = live ? lds_load(&g_ids[k0 + lane]) : 0u;
+                        v = (ARG_UNIT && live) ? lds_load(&g_val[k0 + lane]) : 0.0f;
+                    }
+                    bool hit = false;
+                    const uint32_t rt = rank_in(t_tab, x, hit);
+                    hit = hit && live;
+                    const bool single = live && !hit;
+                    bool drop = OP == SDRB_OP_XOR && hit;   // id-only xore drops every match
+                    if constexpr (DROP_BY_VALUE) {
+                        if (hit) {
+                            const float tv = lds_load(&t_val[rt]);
+                            drop = !match_kept<OP, THIS_UNIT>(match_data<OP, ARG_UNIT>(tv, ARG_UNIT ? v : 0.0f));
+                        }
+                    }
+                    uint32_t n_single, n_drop = 0;
+                    uint32_t pos = rt + singles + prefix_of(single, n_single);
+                    if constexpr (OP == SDRB_OP_XOR) pos -= dropped + prefix_of(drop, n_drop);
+                    if (single) {
+                        out_ids[base + pos] = (int32_t)x;
+                        if constexpr (THIS_UNIT) out_data[base + pos] = ARG_UNIT ? v : 1.0f;
+                    }
+                    singles += n_single;
+                    dropped += n_drop;
+                }
+            }
+        }
+    }
+}
+
+struct Args {
+    const sdrb_batch* a;
+    const sdrb_batch* b;
+    const RankEntry* a_tab;
+    const uint32_t* out_off;
+    int32_t* out_ids;
+    float* out_data;
+    uint32_t nw, qc, cap_a, cap_b, rows_per_wave;
+    dim3 grid;
+    size_t lds;
+    hipStream_t stream;
+};
+
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+void launch(const Args& g) {
+    hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
+                       g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets, g.b->d_ids, g.b->d_data,
+                       (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc, g.cap_a, g.cap_b, g.rows_per_wave);
+}
+
+template <int OP, bool SWAP>
+void launch_kinds(const Args& g) {
+    const bool au = g.a->data_kind == SDRB_DATA_UNIT, bu = g.b->data_kind == SDRB_DATA_UNIT;
+    if (au && bu) launch<OP, SWAP, true, true>(g);
+    else if (au) launch<OP, SWAP, true, false>(g);
+    else if (bu) launch<OP, SWAP, false, true>(g);
+    else launch<OP, SWAP, false, false>(g);
+}
+
+template <int OP>
+void launch_swap(const Args& g, bool swap) {
+    if (swap) launch_kinds<OP, true>(g);
+    else launch_kinds<OP, false>(g);
+}
+
+constexpr int32_t kMaxWidth = 32768;           // 8 KiB of table per row
+constexpr size_t kMaxTableBytes = 512u << 20;  // tables of A in global memory
+constexpr size_t kLdsWanted = 64 * 1024;       // rows of A per block are halved until a block fits this
+constexpr size_t kLdsLimit = 64 * 1024;        // what a block may use at most
+
+struct Shape {
+    uint32_t nw, qc, cap_a, cap_b;
+    size_t lds;
+    bool ok;
+};
+
+size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b) {
+    return ((size_t)kWaves * nw + (size_t)qc * nw) * sizeof(RankEntry) + ((size_t)qc * cap_a + (size_t)kWaves * cap_b) * 8;
+}
+
+// rows of A per block: up to kQueryChunk, fewer when tables and rows are large (a row of B's table is
+// rebuilt for every block that visits it, so more rows of A per block beat more blocks per compute unit)
+Shape shape_for(const sdrb_batch* a, const sdrb_batch* b) {
+    Shape s;
+    s.nw = (uint32_t)(((size_t)b->width + 31) / 32);
+    s.cap_a = (a->max_row_len + 63) / 64 * 64;
+    s.cap_b = (b->max_row_len + 63) / 64 * 64;
+    if (s.cap_a == 0) s.cap_a = 64;
+    if (s.cap_b == 0) s.cap_b = 64;
+    s.qc = kQueryChunk;
+    while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b) > kLdsWanted) s.qc >>= 1;
+    s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b);
+    s.ok = s.lds <= kLdsLimit;
+    return s;
+}
+
+}  // namespace
+
+bool elem_rank_applicable(const sdrb_batch* a, const sdrb_batch* b) {
+    if (a->id_bits != 32 || b->id_bits != 32) return false;
+    if (b->width <= 0 || b->width > kMaxWidth) return false;
+    const Shape s = shape_for(a, b);
+    if (!s.ok) return false;                                                   // rows too long to stage in LDS
+    if (a->n_rows > 65535ull * s.qc || b->n_rows > 0xffffffffull) return false;   // grid.y limit
+    if (a->nnz && (a->min_id < 0 || a->max_id >= b->width)) return false;      // every id needs a bit
+    return (size_t)a->n_rows * s.nw * sizeof(RankEntry) <= kMaxTableBytes;
+}
+
+int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
+                     int32_t* out_ids, float* out_data, hipStream_t stream) {
+    const Shape shape = shape_for(a, b);
+    const uint32_t nw = shape.nw;
+    RankEntry* a_tab = static_cast<RankEntry*>(workspace(b->device, 9, (size_t)a->n_rows * nw * sizeof(RankEntry)));
+    if (!a_tab) return SDRB_ERR_HIP;
+    hipLaunchKernelGGL(k_build_rank_tables, dim3((uint32_t)a->n_rows), dim3(kBlock), nw * sizeof(uint32_t), stream,
+                       a->d_offsets, a->d_ids, nw, a_tab);
+    SDRB_HIP(hipGetLastError());
+
+    Args g;
+    g.a = a;
+    g.b = b;
+    g.a_tab = a_tab;
+    g.out_off = out_offsets;
+    g.out_ids = out_ids;
+    g.out_data = out_data;
+    g.nw = nw;
+    g.qc = shape.qc;
+    g.cap_a = shape.cap_a;
+    g.cap_b = shape.cap_b;
+    g.lds = shape.lds;
+    g.stream = stream;
+    // enough waves to fill the chip, few enough that each amortises its tables
+    const uint64_t nb = b->n_rows;
+    const uint64_t ychunks = (a->n_rows + g.qc - 1) / g.qc;
+    uint32_t rpw = 16;
+    while (rpw > 1 && (nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves) * ychunks < 4096) rpw >>= 1;
+    g.rows_per_wave = rpw;
+    g.grid = dim3((uint32_t)((nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves)), (uint32_t)ychunks);
+    switch (op) {
+    case SDRB_OP_AND: launch_swap<SDRB_OP_AND>(g, swap); break;
+    case SDRB_OP_OR: launch_swap<SDRB_OP_OR>(g, swap); break;
+    case SDRB_OP_XOR: launch_swap<SDRB_OP_XOR>(g, swap); break;
+    case SDRB_OP_RM: launch_swap<SDRB_OP_RM>(g, swap); break;
+    default: set_error("unknown op %d", op); return SDRB_ERR_INVALID_ARG;
+    }
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+}  // namespace sdrb

@@ -39,7 +39,7 @@ void set_error(const char* fmt, ...);
 // slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
 // slot 4: partial top-k lists; slot 5: interleaved value table of A (dot products);
 // slot 6: dense payload matrix of A (mask-table kernel); slot 7: staged range / point queries;
-// slot 8: sort buffers of the transpose.
+// slot 8: sort buffers of the transpose; slot 9: rank tables of A (wave-per-pair element fill).
 void* workspace(int device, int slot, size_t bytes);
 
 #define SDRB_HIP(call)                                                                   \
@@ -83,6 +83,13 @@ int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
 bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);
 int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                        const uint32_t* out_offsets, int32_t* out_ids, hipStream_t stream);
+
+// elem_rank.hip --------------------------------------------------------------------
+// Wave-per-pair fill from rank tables (bitset + popcount prefix per row): any payload kinds, all four
+// ops, declared width <= 32768.
+bool elem_rank_applicable(const sdrb_batch* a, const sdrb_batch* b);
+int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
+                     int32_t* out_ids, float* out_data, hipStream_t stream);
 
 // size_popcount.hip ------------------------------------------------------------------
 // Dense-bitset popcount size ops (id-only results, declared width <= 2048).

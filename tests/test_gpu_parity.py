@@ -270,6 +270,36 @@ def test_table_kernels_with_declared_width_vs_oracle(name, width, len_a, len_b):
                               util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
 
 
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("width,len_a,len_b,nq,nd", [(2048, 40, 40, 37, 301), (16384, 400, 400, 19, 130), (63, 63, 63, 20, 90),
+                                                   (32768, 90, 700, 5, 77), (20000, 300, 100, 33, 50), (640, 640, 5, 17, 64), (4100, 0, 50, 3, 40)])
+def test_rank_table_element_kernel_vs_oracle(name, width, len_a, len_b, nq, nd):
+    # wave-per-pair fill: positions come from rank tables; every op, payload pairing and orientation
+    # must equal the oracle's merge bit for bit, rows longer than a wave and empty rows included
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(width + len_a + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, nq, width, len_a, tu))
+    a = Batch(*util.ragged_rows(rng, nd, width, len_b, au))
+    dt, da = dev(t, width), dev(a, width)
+    for op in range(4):
+        assert_elems_equal(gpu_elems(op, dt, da, algo="rank"), oracle.port().elem_op(op, t, a))
+        off, ids, data = gpu_elems(op, dt, da, swap=True, algo="rank")
+        w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
+        assert np.array_equal(np.diff(off).reshape(t.n, a.n), np.diff(w_off).reshape(a.n, t.n).T)
+        assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
+                              util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
+
+
+def test_rank_table_kernel_refuses_what_it_cannot_hold():
+    rng = np.random.default_rng(3)
+    t = Batch(*util.ragged_rows(rng, 4, 300, 20, False))
+    a = Batch(*util.ragged_rows(rng, 9, 200, 20, False))
+    with pytest.raises(sdr_amd.SdrbError):          # ids of `this` beyond the declared width of the other side
+        gpu_elems(OR, dev(t, 300), dev(a, 200), algo="rank")
+    with pytest.raises(sdr_amd.SdrbError):          # no declared width
+        gpu_elems(OR, dev(a), dev(a), algo="rank")
+
+
 @pytest.mark.parametrize("width,max_len,nq,nd", [(2048, 40, 70, 700), (2048, 2048, 9, 300), (1000, 600, 33, 513),
                                                  (300, 300, 1, 257), (64, 64, 130, 100)])
 @pytest.mark.parametrize("au", [False, True])

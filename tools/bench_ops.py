@@ -38,13 +38,19 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cases", default="c3,c4")
     ap.add_argument("--only", default="", help="comma-separated size-op names to run (default: all four)")
+    ap.add_argument("--algo", default=None, help="force a kernel family for the element ops (e.g. merge, rank, rowtable)")
     args = ap.parse_args()
     cases = []
-    if "c3" in args.cases:
+    if "c3" in args.cases.split(","):
         for nq in (1, 16):
             cases.append(("c3", nq, args.rows, 2048, 40, False))
-    if "c4" in args.cases:
+    if "c3u" in args.cases:      # the configs[2] shape with UnitData payloads on both sides
+        for nq in (1, 16):
+            cases.append(("c3u", nq, args.rows, 2048, 40, True))
+    if "c4" in args.cases.split(","):
         cases.append(("c4", 64, args.rows // 8, 16384, 328, True))
+    if "c4q" in args.cases:      # configs[3] with 24 queries, so that the unions fit 32-bit offsets
+        cases.append(("c4q", 24, args.rows // 8, 16384, 328, True))
     only = set(args.only.split(",")) if args.only else None
     for tag, nq, nd, width, active, unit in cases:
         q = SDRBatch.from_csr(*sdr_amd.synth_csr(2, 0, nq, width, active, unit), width=width)
@@ -56,7 +62,7 @@ def main():
                 continue
             ms_s, counts = timed(lambda: getattr(q, sname)(d), args.reps)
             try:
-                ms_e, res = timed(lambda: getattr(q, ename)(d), args.reps)
+                ms_e, res = timed(lambda: getattr(q, ename)(d, algo=args.algo), args.reps)
             except sdr_amd.SdrbError as e:      # e.g. a union too large for 32-bit offsets: size op only
                 print(json.dumps({"case": tag, "queries": nq, "rows": nd, "size_op": sname, "size_ms": round(ms_s, 4),
                                   "size_GBps": round((in_bytes + nq * nd * 4) / ms_s / 1e6, 1),
