@@ -42,6 +42,7 @@ extern "C" {
 #define SDRB_ERR_PAYLOAD_RANGE (-7) /* a UnitData payload outside [0,1] (UnitData.hpp:15-17) */
 #define SDRB_ERR_IO (-8)            /* a file could not be opened, read or written */
 #define SDRB_ERR_FORMAT (-9)        /* not a CSR database file, or its tables are inconsistent */
+#define SDRB_ERR_NO_MEMORY (-10)    /* a host allocation failed */
 
 /* set operations */
 #define SDRB_OP_AND 0

@@ -27,6 +27,7 @@ ERROR_NAMES = {
     -7: "SDRB_ERR_PAYLOAD_RANGE",
     -8: "SDRB_ERR_IO",
     -9: "SDRB_ERR_FORMAT",
+    -10: "SDRB_ERR_NO_MEMORY",
 }
 
 

@@ -234,7 +234,7 @@ int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out
     sdrb_batch* b = new (std::nothrow) sdrb_batch();
     if (!b) {
         set_error("out of host memory");
-        return SDRB_ERR_INVALID_ARG;
+        return SDRB_ERR_NO_MEMORY;
     }
     b->device = device;
     b->width = width;
@@ -253,7 +253,7 @@ int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out) {
     return rc;
 }
 
-int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
+static int sdrb_batch_upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
                             const int64_t* ids, const float* data, void* stream) {
     if (!batch || !row_offsets || batch->id_bits != 64) {
         set_error("sdrb_batch_upload_csr64: null argument or not a 64-bit batch");
@@ -316,7 +316,11 @@ int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* 
     return SDRB_OK;
 }
 
-int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
+int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets, const int64_t* ids, const float* data, void* stream) {
+    return sdrb::guarded("sdrb_batch_upload_csr64", [&] { return sdrb_batch_upload_csr64_impl(batch, n_rows, row_offsets, ids, data, stream); });
+}
+
+static int sdrb_batch_upload_csr_impl(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
                           const int32_t* ids, const float* data, void* stream) {
     if (!batch || !row_offsets) {
         set_error("sdrb_batch_upload_csr: null argument");
@@ -421,6 +425,10 @@ int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* ro
     batch->min_id = min_id;
     batch->max_id = max_id;
     return SDRB_OK;
+}
+
+int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids, const float* data, void* stream) {
+    return sdrb::guarded("sdrb_batch_upload_csr", [&] { return sdrb_batch_upload_csr_impl(batch, n_rows, row_offsets, ids, data, stream); });
 }
 
 int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint32_t* row_offsets,
@@ -645,7 +653,7 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
 }
 
-int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
+static int sdrb_batch_transpose_impl(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
     if (!src || !dst || src == dst || !src->d_offsets) {
         set_error("sdrb_batch_transpose: null, identical or empty handles");
         return SDRB_ERR_INVALID_ARG;
@@ -679,6 +687,10 @@ int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
     dst->min_id = 0;                                   // bounds of the row numbers (not necessarily attained)
     dst->max_id = src->nnz ? (int32_t)src->n_rows - 1 : -1;
     return SDRB_OK;
+}
+
+int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
+    return sdrb::guarded("sdrb_batch_transpose", [&] { return sdrb_batch_transpose_impl(src, dst, stream); });
 }
 
 namespace {
@@ -987,7 +999,7 @@ int sdrb_stream_sync(int device, void* stream) {
     return SDRB_OK;
 }
 
-int sdrb_synth_csr(uint64_t seed, uint64_t first_row, uint64_t n_rows, int32_t width,
+static int sdrb_synth_csr_impl(uint64_t seed, uint64_t first_row, uint64_t n_rows, int32_t width,
                    int32_t active, uint64_t* row_offsets, int32_t* ids, float* data) {
     if (width <= 0 || active < 0 || active > width || !row_offsets || (!ids && n_rows && active)) {
         set_error("sdrb_synth_csr: bad argument (width=%d active=%d)", width, active);
@@ -1025,6 +1037,10 @@ int sdrb_synth_csr(uint64_t seed, uint64_t first_row, uint64_t n_rows, int32_t w
     }
     row_offsets[n_rows] = n_rows * (uint64_t)active;
     return SDRB_OK;
+}
+
+int sdrb_synth_csr(uint64_t seed, uint64_t first_row, uint64_t n_rows, int32_t width, int32_t active, uint64_t* row_offsets, int32_t* ids, float* data) {
+    return sdrb::guarded("sdrb_synth_csr", [&] { return sdrb_synth_csr_impl(seed, first_row, n_rows, width, active, row_offsets, ids, data); });
 }
 
 }  // extern "C"

@@ -160,12 +160,12 @@ struct sdrb_file_writer {
 
 extern "C" {
 
-int sdrb_file_writer_open(const char* path, int32_t width, int data_kind, sdrb_file_writer** out) {
+static int sdrb_file_writer_open_impl(const char* path, int32_t width, int data_kind, sdrb_file_writer** out) {
     if (!path || !out || width < 0 || (data_kind != SDRB_DATA_EMPTY && data_kind != SDRB_DATA_UNIT && data_kind != SDRB_DATA_ARITH)) {
         set_error("sdrb_file_writer_open: bad argument");
         return SDRB_ERR_INVALID_ARG;
     }
-    sdrb_file_writer* w = new sdrb_file_writer;
+    sdrb_file_writer* w = new sdrb_file_writer;   // a failed allocation is reported by the entry point's guard
     w->path = path;
     w->width = width;
     w->unit = data_kind != SDRB_DATA_EMPTY;
@@ -197,7 +197,11 @@ int sdrb_file_writer_open(const char* path, int32_t width, int data_kind, sdrb_f
     return SDRB_OK;
 }
 
-int sdrb_file_writer_append(sdrb_file_writer* w, uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids,
+int sdrb_file_writer_open(const char* path, int32_t width, int data_kind, sdrb_file_writer** out) {
+    return sdrb::guarded("sdrb_file_writer_open", [&] { return sdrb_file_writer_open_impl(path, width, data_kind, out); });
+}
+
+static int sdrb_file_writer_append_impl(sdrb_file_writer* w, uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids,
                             const float* data) {
     if (!w || !row_offsets || row_offsets[0] != 0) {
         set_error("sdrb_file_writer_append: null argument or row_offsets[0] != 0");
@@ -245,7 +249,11 @@ int sdrb_file_writer_append(sdrb_file_writer* w, uint64_t n_rows, const uint64_t
     return SDRB_OK;
 }
 
-int sdrb_file_writer_close(sdrb_file_writer* w) {
+int sdrb_file_writer_append(sdrb_file_writer* w, uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids, const float* data) {
+    return sdrb::guarded("sdrb_file_writer_append", [&] { return sdrb_file_writer_append_impl(w, n_rows, row_offsets, ids, data); });
+}
+
+static int sdrb_file_writer_close_impl(sdrb_file_writer* w) {
     if (!w) return SDRB_OK;
     Header h{};
     std::memcpy(h.magic, kMagic, 8);
@@ -294,6 +302,10 @@ int sdrb_file_writer_close(sdrb_file_writer* w) {
     sdrb_file_writer_abort(w);
     set_error("finishing %s failed: %s", path.c_str(), std::strerror(saved));
     return SDRB_ERR_IO;
+}
+
+int sdrb_file_writer_close(sdrb_file_writer* w) {
+    return sdrb::guarded("sdrb_file_writer_close", [&] { return sdrb_file_writer_close_impl(w); });
 }
 
 int sdrb_file_writer_abort(sdrb_file_writer* w) {
@@ -353,7 +365,7 @@ int sdrb_file_read_rows(const char* path, uint64_t row_lo, uint64_t row_hi, uint
     return SDRB_OK;
 }
 
-int sdrb_batch_upload_file(sdrb_batch* batch, const char* path, uint64_t row_lo, uint64_t row_hi, void* stream) {
+static int sdrb_batch_upload_file_impl(sdrb_batch* batch, const char* path, uint64_t row_lo, uint64_t row_hi, void* stream) {
     if (!batch) {
         set_error("null batch handle");
         return SDRB_ERR_INVALID_ARG;
@@ -378,6 +390,10 @@ int sdrb_batch_upload_file(sdrb_batch* batch, const char* path, uint64_t row_lo,
     for (uint64_t r = row_lo; r <= row_hi; ++r) off[r - row_lo] = m.offsets[r] - e0;
     return sdrb_batch_upload_csr(batch, row_hi - row_lo, off.data(), m.ids + e0,
                                  sdrb::has_payload(batch) ? m.data + e0 : nullptr, stream);
+}
+
+int sdrb_batch_upload_file(sdrb_batch* batch, const char* path, uint64_t row_lo, uint64_t row_hi, void* stream) {
+    return sdrb::guarded("sdrb_batch_upload_file", [&] { return sdrb_batch_upload_file_impl(batch, path, row_lo, row_hi, stream); });
 }
 
 }  // extern "C"

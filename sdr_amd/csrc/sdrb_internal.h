@@ -3,6 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <exception>
+#include <new>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -34,6 +37,24 @@ namespace sdrb {
 inline bool has_payload(const sdrb_batch* b) { return b->data_kind != SDRB_DATA_EMPTY; }
 
 void set_error(const char* fmt, ...);
+
+// Runs `body` (a callable returning a status code) so that nothing is thrown through the C ABI: a failed
+// host allocation or any other C++ exception becomes a status code and a message.
+template <typename F>
+int guarded(const char* what, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", what);
+        return SDRB_ERR_NO_MEMORY;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return SDRB_ERR_INVALID_ARG;
+    } catch (...) {
+        set_error("%s: unexpected exception", what);
+        return SDRB_ERR_INVALID_ARG;
+    }
+}
 
 // Per-device scratch that grows on demand and lives until process exit.
 // slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
