@@ -367,6 +367,23 @@ class SDRBatch {
     SDRBatch& xori(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_XOR, arg, stream); }
     SDRBatch& rmi(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_RM, arg, stream); }
 
+    // The reference's operator sugar (SDR.hpp:431-460), batch against batch: & * -> ande, && -> ands,
+    // | + -> ore, || -> ors, ^ -> xore, - -> rme for every pair; &= *= |= += ^= -= -> the in-place forms row by row.
+    Elements operator&(const SDRBatch& o) const { return ande(o); }
+    Elements operator*(const SDRBatch& o) const { return ande(o); }
+    Counts operator&&(const SDRBatch& o) const { return ands(o); }
+    Elements operator|(const SDRBatch& o) const { return ore(o); }
+    Elements operator+(const SDRBatch& o) const { return ore(o); }
+    Counts operator||(const SDRBatch& o) const { return ors(o); }
+    Elements operator^(const SDRBatch& o) const { return xore(o); }
+    Elements operator-(const SDRBatch& o) const { return rme(o); }
+    SDRBatch& operator&=(const SDRBatch& o) { return andi(o); }
+    SDRBatch& operator*=(const SDRBatch& o) { return andi(o); }
+    SDRBatch& operator|=(const SDRBatch& o) { return ori(o); }
+    SDRBatch& operator+=(const SDRBatch& o) { return ori(o); }
+    SDRBatch& operator^=(const SDRBatch& o) { return xori(o); }
+    SDRBatch& operator-=(const SDRBatch& o) { return rmi(o); }
+
     // Range queries: out(r, j) = (*this)[j].ands(lo[r], hi[r]), the ids of row j in [lo, hi) (SDR.hpp:931-956),
     // and the elements themselves, (*this)[j].ande(lo[r], hi[r]) (SDR.hpp:881-929), as a CSR over (r, j).
     Counts range_size(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, void* stream = nullptr) const {

@@ -413,6 +413,44 @@ class SDRBatch:
         """Every row becomes ``row.rmi(other[j])`` (SDR.hpp:1436-1513)."""
         return self._inplace("rme", other, stream)
 
+    # The reference's operator sugar (SDR.hpp:431-460), batch against batch.  Python has no overloadable
+    # && and ||, so the size ops keep their names.
+    def __and__(self, other):
+        return self.ande(other)
+
+    def __mul__(self, other):
+        return self.ande(other)
+
+    def __or__(self, other):
+        return self.ore(other)
+
+    def __add__(self, other):
+        return self.ore(other)
+
+    def __xor__(self, other):
+        return self.xore(other)
+
+    def __sub__(self, other):
+        return self.rme(other)
+
+    def __iand__(self, other):
+        return self.andi(other)
+
+    def __imul__(self, other):
+        return self.andi(other)
+
+    def __ior__(self, other):
+        return self.ori(other)
+
+    def __iadd__(self, other):
+        return self.ori(other)
+
+    def __ixor__(self, other):
+        return self.xori(other)
+
+    def __isub__(self, other):
+        return self.rmi(other)
+
     def ande(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
         return self._elem_op(OP_AND, other, swap, stream, algo)
 

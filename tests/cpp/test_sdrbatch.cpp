@@ -243,6 +243,50 @@ int run_queries(std::mt19937& rng, const char* name) {
     return 0;
 }
 
+// operator sugar (SDR.hpp:431-460) on batches equals the reference's operators on every pair / row
+int run_operators(std::mt19937& rng, const char* name) {
+    using U = SDRElem<int, UnitData>;
+    using R = SDR<U>;
+    auto as = make_rows<R>(rng, 25, 90, 30), bs = make_rows<R>(rng, 25, 90, 30);
+    auto a = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 90);
+    auto b = sdr_amd::SDRBatch::pack(bs.begin(), bs.end(), 0, 90);
+    auto h_and = (a & b).to_host(), h_mul = (a * b).to_host(), h_or = (a | b).to_host(), h_add = (a + b).to_host();
+    auto h_xor = (a ^ b).to_host(), h_sub = (a - b).to_host();
+    auto c_and = (a && b).to_host(), c_or = (a || b).to_host();
+    for (size_t i = 0; i < as.size(); ++i)
+        for (size_t j = 0; j < bs.size(); ++j) {
+            const size_t k = i * bs.size() + j;
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_and, bs.size(), i, j) == (as[i] & bs[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_mul, bs.size(), i, j) == (as[i] * bs[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_or, bs.size(), i, j) == (as[i] | bs[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_add, bs.size(), i, j) == (as[i] + bs[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_xor, bs.size(), i, j) == (as[i] ^ bs[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_sub, bs.size(), i, j) == (as[i] - bs[j]));
+            REQUIRE(c_and[k] == (as[i] && bs[j]));
+            REQUIRE(c_or[k] == (as[i] || bs[j]));
+        }
+    std::vector<R> want(as);
+    for (size_t j = 0; j < want.size(); ++j) {
+        want[j] &= bs[j];
+        want[j] |= as[j];
+        want[j] ^= bs[j];
+        want[j] -= as[j];
+        want[j] += bs[j];
+        want[j] *= as[j];
+    }
+    auto c = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 90);
+    c &= b;
+    c |= a;
+    c ^= b;
+    c -= a;
+    c += b;
+    c *= a;
+    auto h = c.to_host();
+    for (size_t j = 0; j < want.size(); ++j) REQUIRE(sdr_amd::Elements::unpack<R>(h, want.size(), 0, j) == want[j]);
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
 // database files: SDR objects -> file -> SDR objects (reference operator==), and a batch loaded from
 // a row range of the file gives the reference's counts
 template <typename SDR_t>
@@ -298,6 +342,7 @@ int main() {
         if (run_inplace<SDR<U>, SDR<U>>(rng, "in-place unit x unit")) return 1;
         if (run_inplace<SDR<U>, SDR<E>>(rng, "in-place unit x empty")) return 1;
         if (run_queries(rng, "range/point/transpose")) return 1;
+        if (run_operators(rng, "operator sugar")) return 1;
         if (run_file<SDR<E>>(rng, "file_empty")) return 1;
         if (run_file<SDR<U>>(rng, "file_unit")) return 1;
         if (run_file<SDR<AE>>(rng, "file_arith")) return 1;

@@ -212,6 +212,24 @@ def test_readme_examples_on_device():
     assert ids.tolist() == [0] and data.tolist() == [0.5]
 
 
+def test_operator_sugar_matches_the_named_ops():
+    # SDR.hpp:431-460: & * -> ande, | + -> ore, ^ -> xore, - -> rme; the augmented forms are the in-place ops
+    rng = np.random.default_rng(5)
+    t = Batch(*util.ragged_rows(rng, 30, 100, 30, True))
+    a = Batch(*util.ragged_rows(rng, 30, 100, 30, True))
+    dt, da = dev(t, 100), dev(a, 100)
+    for sugar, op in ((dt & da, AND), (dt * da, AND), (dt | da, OR), (dt + da, OR), (dt ^ da, XOR), (dt - da, RM)):
+        assert_elems_equal(sugar.to_host(), oracle.port().elem_op(op, t, a))
+    c = dev(t, 100)
+    c &= da
+    c |= dt
+    c ^= da
+    c -= dt
+    want = dev(t, 100).andi(da).ori(dt).xori(da).rmi(dt)
+    assert c.n_rows == want.n_rows and c.nnz == want.nnz
+    assert np.array_equal(c.to_wire().cpu().numpy(), want.to_wire().cpu().numpy())   # offsets, ids, payload bits
+
+
 @pytest.mark.parametrize("width,max_len", [(2048, 40), (4096, 100), (100, 100), (33, 20)])
 @pytest.mark.parametrize("au", [False, True])
 def test_bitset_element_kernel_vs_oracle(width, max_len, au):
