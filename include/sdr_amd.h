@@ -255,6 +255,25 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
                       void* stream);
 
 /*
+ * Batched visitors: what the reference's extension API hands to its callbacks (README.md:133-155), for
+ * every pair, as arrays -- the raw material for operations the library does not have.
+ *   SDRB_VISIT_AND -> andv (SDR.hpp:186-194, 958-997): one record per id match, ascending by id:
+ *                     (position in `this`, position in `arg`)
+ *   SDRB_VISIT_OR  -> orv (SDR.hpp:268-285, 1099-1166): one record per id of the union, ascending: a match,
+ *                     or a single whose absent side is SDRB_POS_NONE (this_visitor / arg_visitor / both_visitor)
+ * Positions index the rows' elements (ids[row_offsets[r] + position], data[...] likewise); payloads play no part,
+ * so batches of any payload kind are taken.  Same two-call protocol, orientation and flags (SDRB_FLAG_SWAP,
+ * SDRB_FLAG_ROWWISE, SDRB_FLAG_FORCE_MERGE) as the element ops; ids of 32 or 64 bits.
+ */
+#define SDRB_VISIT_AND 0
+#define SDRB_VISIT_OR 1
+#define SDRB_POS_NONE 0xFFFFFFFFu
+int sdrb_visit_count(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, uint32_t* out_offsets,
+                     uint64_t* total, void* stream);
+int sdrb_visit_fill(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, const uint32_t* out_offsets,
+                    uint32_t* this_pos, uint32_t* arg_pos, void* stream);
+
+/*
  * Device-memory helpers for callers that do not link a HIP runtime themselves (the C++
  * SDRBatch front end, ctypes/cgo/JNI bindings).  sdrb_memcpy_* synchronise.
  */

@@ -207,6 +207,27 @@ class TopK {
     detail::DeviceBuffer counts_, rows_;
 };
 
+// What the reference's visitors are called with (andv / orv), for all pairs: pair (i, j) owns the records
+// offsets[i*nb+j] .. offsets[i*nb+j+1], each a (position in this, position in arg); SDRB_POS_NONE marks the
+// absent side of an orv single.
+class Visits {
+ public:
+    size_t na = 0, nb = 0;
+    uint64_t total = 0;
+    detail::DeviceBuffer offsets, this_pos, arg_pos;
+
+    struct Host {
+        std::vector<uint32_t> offsets, this_pos, arg_pos;
+    };
+    Host to_host(void* stream = nullptr) const {
+        Host h;
+        h.offsets = offsets.to_host<uint32_t>(na * nb + 1, stream);
+        h.this_pos = this_pos.to_host<uint32_t>(total, stream);
+        h.arg_pos = arg_pos.to_host<uint32_t>(total, stream);
+        return h;
+    }
+};
+
 // CSR result of an element op over all pairs
 class Elements {
  public:
@@ -367,6 +388,12 @@ class SDRBatch {
     SDRBatch& xori(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_XOR, arg, stream); }
     SDRBatch& rmi(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_RM, arg, stream); }
 
+    // Batched visitors (the reference's extension API, README.md:133-155): the calls that
+    // (*this)[i].andv(db[j], visitor) (SDR.hpp:186-194) and (*this)[i].orv(db[j], this_v, arg_v, both_v)
+    // (SDR.hpp:268-269) make, as arrays of element positions -- the raw material for custom operations.
+    Visits andv(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return visit(SDRB_VISIT_AND, db, flags, stream); }
+    Visits orv(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return visit(SDRB_VISIT_OR, db, flags, stream); }
+
     // The reference's operator sugar (SDR.hpp:431-460), batch against batch: & * -> ande, && -> ands,
     // | + -> ore, || -> ors, ^ -> xore, - -> rme for every pair; &= *= |= += ^= -= -> the in-place forms row by row.
     Elements operator&(const SDRBatch& o) const { return ande(o); }
@@ -472,6 +499,18 @@ class SDRBatch {
                                     static_cast<int32_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
         }
         return e;
+    }
+    Visits visit(int which, const SDRBatch& db, unsigned flags, void* stream) const {
+        Visits v;
+        v.na = (flags & SDRB_FLAG_ROWWISE) ? 1 : n_rows_;
+        v.nb = db.n_rows_;
+        v.offsets = detail::DeviceBuffer(db.device_, (v.na * v.nb + 1) * sizeof(uint32_t));
+        check(sdrb_visit_count(h_, db.h_, which, flags, static_cast<uint32_t*>(v.offsets.ptr), &v.total, stream));
+        v.this_pos = detail::DeviceBuffer(db.device_, (v.total ? v.total : 1) * sizeof(uint32_t));
+        v.arg_pos = detail::DeviceBuffer(db.device_, (v.total ? v.total : 1) * sizeof(uint32_t));
+        check(sdrb_visit_fill(h_, db.h_, which, flags, static_cast<const uint32_t*>(v.offsets.ptr),
+                              static_cast<uint32_t*>(v.this_pos.ptr), static_cast<uint32_t*>(v.arg_pos.ptr), stream));
+        return v;
     }
     SDRBatch& inplace(int op, const SDRBatch& arg, void* stream) {
         if (id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "in-place operations serve batches of 32-bit ids");

@@ -194,6 +194,22 @@ class _Impl:
            a.data.ctypes.data_as(_vp) if a.data is not None else None, a.n, out.ctypes.data_as(_vp))
         return out
 
+    def visit(self, which: int, t: Batch, a: Batch):
+        """The callbacks of andv (``which`` 0) / orv (``which`` 1) of every pair, in call order:
+        (offsets uint64 [t.n*a.n+1], this_pos uint32, arg_pos uint32); 0xFFFFFFFF marks the absent side of
+        an orv single.  Payloads play no part."""
+        fn = getattr(self.lib, self.prefix + "batch_visit")
+        fn.restype = C.c_uint64
+        fn.argtypes = [C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, _vp, _vp]
+        off = np.zeros(t.n * a.n + 1, dtype=np.uint64)
+        ids = [t.off.ctypes.data_as(_vp), t.ids.ctypes.data_as(_vp), t.n, a.off.ctypes.data_as(_vp),
+               a.ids.ctypes.data_as(_vp), a.n]
+        total = fn(which, *ids, off.ctypes.data_as(_vp), None, None)
+        tp = np.zeros(total, dtype=np.uint32)
+        ap = np.zeros(total, dtype=np.uint32)
+        fn(which, *ids, off.ctypes.data_as(_vp), tp.ctypes.data_as(_vp), ap.ctypes.data_as(_vp))
+        return off, tp, ap
+
     def elem_op(self, op: int, t: Batch, a: Batch, inplace: bool = False):
         """Returns (offsets uint64[t.n*a.n+1], ids, data-or-None) of this_i.op(arg_j)."""
         fn = getattr(self.lib, self.prefix + "batch_elem_op")

@@ -322,6 +322,42 @@ void rsdr_batch_point(const uint64_t* off, const int32_t* ids, const float* data
     }
 }
 
+/* What the reference's visitors are called with: andv (which = 0, SDR.hpp:186-194) and orv (which = 1,
+ * SDR.hpp:268-269) on SDR<SDRElem<int, EmptyData>> rows in std::vector containers, every callback recorded
+ * as (this position, arg position); 0xFFFFFFFF marks the absent side of an orv single. */
+uint64_t rsdr_batch_visit(int which, const uint64_t* t_off, const int32_t* t_ids, uint64_t t_n,
+                          const uint64_t* a_off, const int32_t* a_ids, uint64_t a_n,
+                          uint64_t* out_off, uint32_t* this_pos, uint32_t* arg_pos) {
+    std::vector<EmptySDR> t = build<EmptySDR>(t_off, t_ids, nullptr, t_n);
+    std::vector<EmptySDR> a = build<EmptySDR>(a_off, a_ids, nullptr, a_n);
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < t_n; ++i)
+        for (uint64_t j = 0; j < a_n; ++j) {
+            out_off[i * a_n + j] = n;
+            EmptySDR& ti = t[i];
+            EmptySDR& aj = a[j];
+            auto rec = [&](uint32_t tp, uint32_t ap) {
+                if (this_pos) {
+                    this_pos[n] = tp;
+                    arg_pos[n] = ap;
+                }
+                ++n;
+            };
+            auto both = [&](EmptySDR::iterator tp, EmptySDR::iterator ap) {
+                rec((uint32_t)(tp - ti.begin()), (uint32_t)(ap - aj.begin()));
+            };
+            if (which == 0) {
+                ti.andv(aj, both);
+            } else {
+                auto only_this = [&](EmptySDR::iterator tp) { rec((uint32_t)(tp - ti.begin()), 0xFFFFFFFFu); };
+                auto only_arg = [&](EmptySDR::iterator ap) { rec(0xFFFFFFFFu, (uint32_t)(ap - aj.begin())); };
+                ti.orv(aj, only_this, only_arg, both);
+            }
+        }
+    out_off[t_n * a_n] = n;
+    return n;
+}
+
 /* this_i.inner(arg_j) on SDR<SDRElem<int, ArithData<float>>> rows (SDR.hpp:1682-1692); a_data == NULL:
  * the argument rows are SDR<SDRElem<int, EmptyData>>.  Also checks that diff_mul on the same rows,
  * taken as a row-major and a column-major matrix, produces the same entries (SDR.hpp:1886-1923). */

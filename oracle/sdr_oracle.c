@@ -427,6 +427,49 @@ void osdr_batch_inner(const uint64_t* t_off, const int32_t* t_ids, const float* 
         }
 }
 
+/* ---- the visit sequences themselves (what andv / orv hand to their callbacks) ------------- */
+typedef struct {
+    uint32_t* this_pos;
+    uint32_t* arg_pos;
+    uint64_t n;
+} visit_ctx;
+
+static void rec_both(void* p, size_t tp, size_t ap) {
+    visit_ctx* c = (visit_ctx*)p;
+    if (c->this_pos) { c->this_pos[c->n] = (uint32_t)tp; c->arg_pos[c->n] = (uint32_t)ap; }
+    c->n++;
+}
+static void rec_this(void* p, size_t tp) {
+    visit_ctx* c = (visit_ctx*)p;
+    if (c->this_pos) { c->this_pos[c->n] = (uint32_t)tp; c->arg_pos[c->n] = 0xFFFFFFFFu; }
+    c->n++;
+}
+static void rec_arg(void* p, size_t ap) {
+    visit_ctx* c = (visit_ctx*)p;
+    if (c->this_pos) { c->this_pos[c->n] = 0xFFFFFFFFu; c->arg_pos[c->n] = (uint32_t)ap; }
+    c->n++;
+}
+
+/* which = 0: andv (SDR.hpp:958-997), one record per callback (this position, arg position);
+ * which = 1: orv (SDR.hpp:1099-1166), the absent side of a single is 0xFFFFFFFF.
+ * out_off[t_n*a_n + 1]; this_pos / arg_pos may be NULL (count only).  Returns the total. */
+uint64_t osdr_batch_visit(int which, const uint64_t* t_off, const int32_t* t_ids, uint64_t t_n,
+                          const uint64_t* a_off, const int32_t* a_ids, uint64_t a_n,
+                          uint64_t* out_off, uint32_t* this_pos, uint32_t* arg_pos) {
+    visit_ctx c = {this_pos, arg_pos, 0};
+    for (uint64_t i = 0; i < t_n; ++i)
+        for (uint64_t j = 0; j < a_n; ++j) {
+            out_off[i * a_n + j] = c.n;
+            const int32_t* t = t_ids + t_off[i];
+            const int32_t* a = a_ids + a_off[j];
+            const size_t tn = (size_t)(t_off[i + 1] - t_off[i]), an = (size_t)(a_off[j + 1] - a_off[j]);
+            if (which == 0) osdr_andv(t, tn, a, an, rec_both, &c);
+            else osdr_orv(t, tn, a, an, rec_this, rec_arg, rec_both, &c);
+        }
+    out_off[t_n * a_n] = c.n;
+    return c.n;
+}
+
 void osdr_batch_size_op(int op,
                         const uint64_t* t_off, const int32_t* t_ids, const float* t_data,
                         int t_kind, uint64_t t_n,

@@ -107,6 +107,13 @@ uint64_t osdr_batch_elem_op(int op,
                             int a_kind, uint64_t a_n,
                             uint64_t* out_off, int32_t* out_ids, float* out_data);
 
+/* The callbacks of andv (which = 0, SDR.hpp:958-997) or orv (which = 1, SDR.hpp:1099-1166) of every pair, in
+ * call order, as (this position, arg position) records; the absent side of an orv single is 0xFFFFFFFF.
+ * out_off has t_n*a_n+1 entries; this_pos / arg_pos may be NULL (count only).  Returns the total. */
+uint64_t osdr_batch_visit(int which, const uint64_t* t_off, const int32_t* t_ids, uint64_t t_n,
+                          const uint64_t* a_off, const int32_t* a_ids, uint64_t a_n,
+                          uint64_t* out_off, uint32_t* this_pos, uint32_t* arg_pos);
+
 /* Times `repeats` passes of the batched size op on one thread and returns the best
  * wall time in seconds; *checksum receives the sum of all results of one pass. */
 double osdr_time_size_op(int op,

@@ -73,6 +73,26 @@ class ElemResult:
         return off, ids, data
 
 
+@dataclass
+class VisitResult:
+    """What the reference's visitors are called with, for all pairs: pair (i, j) owns records
+    ``offsets[i*nb+j] : offsets[i*nb+j+1]``, each a (position in ``this``, position in ``arg``); the absent
+    side of an ``orv`` single is ``POS_NONE``."""
+    na: int
+    nb: int
+    offsets: "object"            # torch.int32 [na*nb + 1] (values are uint32)
+    this_pos: "object"           # torch.int32 [total] (values are uint32)
+    arg_pos: "object"            # torch.int32 [total]
+    total: int
+
+    def to_host(self):
+        return (self.offsets.cpu().numpy().view(np.uint32).astype(np.uint64),
+                self.this_pos.cpu().numpy().view(np.uint32), self.arg_pos.cpu().numpy().view(np.uint32))
+
+
+POS_NONE = 0xFFFFFFFF
+
+
 class SDRBatch:
     """A device-resident CSR pack of SDRs (ids int32, optional UnitData float payloads)."""
 
@@ -412,6 +432,35 @@ class SDRBatch:
     def rmi(self, other, *, stream=None) -> "SDRBatch":
         """Every row becomes ``row.rmi(other[j])`` (SDR.hpp:1436-1513)."""
         return self._inplace("rme", other, stream)
+
+    # -- batched visitors ------------------------------------------------------------------------
+    def _visit(self, which: int, other: "SDRBatch", swap, stream, algo, rowwise) -> VisitResult:
+        torch = _torch()
+        dev = f"cuda:{other.device}"
+        if rowwise and self.n_rows != other.n_rows:
+            raise ValueError("row-wise evaluation needs batches of equal length")
+        pairs = other.n_rows if rowwise else self.n_rows * other.n_rows
+        s = _stream_handle(other.device, stream)
+        flags = self._flags(swap, algo, rowwise)
+        offsets = torch.empty(pairs + 1, dtype=torch.int32, device=dev)
+        total = C.c_uint64()
+        check(self._lib.sdrb_visit_count(self._h, other._h, which, flags, offsets.data_ptr(), C.byref(total), s))
+        n = int(total.value)
+        tp = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        ap = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        check(self._lib.sdrb_visit_fill(self._h, other._h, which, flags, offsets.data_ptr(), tp.data_ptr(),
+                                        ap.data_ptr(), s))
+        return VisitResult(1 if rowwise else self.n_rows, other.n_rows, offsets, tp[:n], ap[:n], n)
+
+    def andv(self, other: "SDRBatch", *, swap=False, stream=None, algo=None, rowwise=False) -> VisitResult:
+        """For every pair, the calls ``self[i].andv(other[j], visitor)`` makes (SDR.hpp:186-194): one record
+        per common id, ascending -- where it sits in ``self[i]`` and in ``other[j]``."""
+        return self._visit(0, other, swap, stream, algo, rowwise)
+
+    def orv(self, other: "SDRBatch", *, swap=False, stream=None, algo=None, rowwise=False) -> VisitResult:
+        """For every pair, the calls of ``self[i].orv(other[j], this_visitor, arg_visitor, both_visitor)``
+        (SDR.hpp:268-269): one record per id of the union, ascending; ``POS_NONE`` marks the absent side."""
+        return self._visit(1, other, swap, stream, algo, rowwise)
 
     # The reference's operator sugar (SDR.hpp:431-460), batch against batch.  Python has no overloadable
     # && and ||, so the size ops keep their names.

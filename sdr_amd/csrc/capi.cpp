@@ -959,6 +959,78 @@ int sdrb_elem_op_fill64(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
     return elem_op_fill_any(a, b, op, flags, out_offsets, out_ids, 64, out_data, stream);
 }
 
+namespace {
+// A batch seen without its payloads (what the visitors' positions depend on).  Derived data built through
+// the view belongs to the batch it views, so it is handed back.
+struct IdView {
+    sdrb_batch v;
+    const sdrb_batch* src;
+    explicit IdView(const sdrb_batch* s) : v(*s), src(s) {
+        v.data_kind = SDRB_DATA_EMPTY;
+        v.d_data = nullptr;
+        v.owns_storage = false;
+    }
+    ~IdView() {
+        sdrb_batch* m = const_cast<sdrb_batch*>(src);
+        m->d_bitplanes = v.d_bitplanes;
+        m->d_dense8 = v.d_dense8;
+        m->dense_chunks = v.dense_chunks;
+    }
+};
+
+int check_visit(const sdrb_batch* a, const sdrb_batch* b, int which) {
+    if (!a || !b) {
+        set_error("null batch handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (which != SDRB_VISIT_AND && which != SDRB_VISIT_OR) {
+        set_error("unknown visitor %d", which);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    return SDRB_OK;
+}
+}  // namespace
+
+int sdrb_visit_count(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, uint32_t* out_offsets,
+                     uint64_t* total, void* stream) {
+    const int rc = check_visit(a, b, which);
+    if (rc != SDRB_OK) return rc;
+    IdView va(a), vb(b);
+    // the number of callbacks is the size of the id-only intersection / union
+    return sdrb_elem_op_count(&va.v, &vb.v, which == SDRB_VISIT_AND ? SDRB_OP_AND : SDRB_OP_OR,
+                              flags & (SDRB_FLAG_SWAP | SDRB_FLAG_ROWWISE | SDRB_FLAG_FORCE_MERGE), out_offsets, total, stream);
+}
+
+int sdrb_visit_fill(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, const uint32_t* out_offsets,
+                    uint32_t* this_pos, uint32_t* arg_pos, void* stream) {
+    int rc = check_visit(a, b, which);
+    const int op = which == SDRB_VISIT_AND ? SDRB_OP_AND : SDRB_OP_OR;
+    if (rc == SDRB_OK) rc = check_pair(a, b, op);
+    if (rc != SDRB_OK) return rc;
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+    if (rowwise && a->n_rows != b->n_rows) {
+        set_error("row-wise evaluation needs batches of equal length");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (!out_offsets || !this_pos || !arg_pos) {
+        set_error("sdrb_visit_fill: null output");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    IdView va(a), vb(b);
+    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32 && elem_rank_applicable(&va.v, &vb.v))
+        return launch_elem_rank(&va.v, &vb.v, op, swap, out_offsets, reinterpret_cast<int32_t*>(this_pos),
+                                reinterpret_cast<float*>(arg_pos), s, true);
+    return launch_elem_visit(&va.v, &vb.v, op, swap, out_offsets, this_pos, arg_pos, rowwise, s);
+}
+
 int sdrb_malloc(int device, size_t bytes, void** ptr) {
     if (!ptr) return SDRB_ERR_INVALID_ARG;
     DeviceGuard guard(device);

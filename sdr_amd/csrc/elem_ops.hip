@@ -82,7 +82,10 @@ int scan_level(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t stream) {
     return SDRB_OK;
 }
 
-template <typename ID, int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+// VISIT (ids only, ande / ore): instead of elements, the positions a visitor of andv / orv would be called
+// with -- out_ids (as uint32) gets the position in `this`, out_data (as uint32) the position in `arg`,
+// 0xFFFFFFFF for the absent side of a single.
+template <typename ID, int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false>
 __global__ __launch_bounds__(kBlock) void k_elem_fill(
     const uint32_t* __restrict__ a_off, const ID* __restrict__ a_ids,
     const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
@@ -107,6 +110,13 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
         const ID* ai = a_ids + a_beg;
         const float* ad = A_UNIT ? a_data + a_beg : nullptr;
         uint32_t w = out_off[rowwise ? j : i * nb + j];
+        constexpr uint32_t NONE = 0xFFFFFFFFu;
+        // a visitor's call: positions in A_i and B_j (NONE = absent), stored as (this, arg)
+        auto emit_pos = [&](uint32_t pa, uint32_t pb) {
+            reinterpret_cast<uint32_t*>(out_ids)[w] = SWAP ? pb : pa;
+            reinterpret_cast<uint32_t*>(out_data)[w] = SWAP ? pa : pb;
+            ++w;
+        };
         auto emit = [&](ID id, float d) {
             out_ids[w] = id;
             if constexpr (THIS_UNIT) out_data[w] = d;
@@ -114,6 +124,10 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
         };
         // an element present only in A / only in B
         auto only_a = [&](uint32_t pa) {
+            if constexpr (VISIT) {   // orv's this/arg visitor; andv has none
+                if constexpr (OP == SDRB_OP_OR) emit_pos(pa, NONE);
+                return;
+            }
             const float va = A_UNIT ? ad[pa] : 0.0f;
             if constexpr (!SWAP) {
                 if constexpr (KEEP_THIS_ONLY) emit(ai[pa], va);
@@ -122,6 +136,10 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
             }
         };
         auto only_b = [&](uint32_t pb) {
+            if constexpr (VISIT) {
+                if constexpr (OP == SDRB_OP_OR) emit_pos(NONE, pb);
+                return;
+            }
             const float vb = B_UNIT ? bd[pb] : 0.0f;
             if constexpr (SWAP) {
                 if constexpr (KEEP_THIS_ONLY) emit(bi[pb], vb);
@@ -134,10 +152,14 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
             const ID x = ai[pa];
             const ID y = bi[pb];
             if (x == y) {
-                const float va = A_UNIT ? ad[pa] : 0.0f;
-                const float vb = B_UNIT ? bd[pb] : 0.0f;
-                const float d = SWAP ? match_data<OP, ARG_UNIT>(vb, va) : match_data<OP, ARG_UNIT>(va, vb);
-                if (match_kept<OP, THIS_UNIT>(d)) emit(x, d);
+                if constexpr (VISIT) {
+                    emit_pos(pa, pb);
+                } else {
+                    const float va = A_UNIT ? ad[pa] : 0.0f;
+                    const float vb = B_UNIT ? bd[pb] : 0.0f;
+                    const float d = SWAP ? match_data<OP, ARG_UNIT>(vb, va) : match_data<OP, ARG_UNIT>(va, vb);
+                    if (match_kept<OP, THIS_UNIT>(d)) emit(x, d);
+                }
                 ++pa;
                 ++pb;
             } else if (x < y) {
@@ -210,6 +232,36 @@ int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_
     uint32_t* sums = static_cast<uint32_t*>(workspace(device, 1, (total_sums + 1) * sizeof(uint32_t)));
     if (!sums) return SDRB_ERR_HIP;
     return scan_level(data, n, sums, stream);
+}
+
+namespace {
+template <typename ID, int OP, bool SWAP>
+void launch_visit(const FillArgs& g, uint32_t gx, uint32_t gy) {
+    hipLaunchKernelGGL((k_elem_fill<ID, OP, SWAP, false, false, true>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
+                       g.a->d_offsets, reinterpret_cast<const ID*>(g.a->d_ids), nullptr, g.a->n_rows, g.b->d_offsets,
+                       reinterpret_cast<const ID*>(g.b->d_ids), nullptr, g.b->n_rows, g.out_off,
+                       static_cast<ID*>(g.out_ids), g.out_data, g.rowwise ? 1u : 0u);
+}
+}  // namespace
+
+// op: SDRB_OP_AND (andv) or SDRB_OP_OR (orv); this_pos / arg_pos: uint32 positions, any id width
+int launch_elem_visit(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
+                      uint32_t* this_pos, uint32_t* arg_pos, bool rowwise, hipStream_t stream) {
+    // the kernel indexes its id output by the id type: for 64-bit ids positions are written through a
+    // 32-bit view, which emit_pos does itself, so the output pointers are passed untyped
+    FillArgs g{a, b, out_offsets, this_pos, reinterpret_cast<float*>(arg_pos), rowwise, stream};
+    const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
+    const uint32_t gy = rowwise ? 1u : (uint32_t)(a->n_rows < 65535 ? a->n_rows : 65535);
+    const bool wide = a->id_bits == 64, is_and = op == SDRB_OP_AND;
+    if (wide) {
+        if (is_and) { if (swap) launch_visit<long long, SDRB_OP_AND, true>(g, gx, gy); else launch_visit<long long, SDRB_OP_AND, false>(g, gx, gy); }
+        else { if (swap) launch_visit<long long, SDRB_OP_OR, true>(g, gx, gy); else launch_visit<long long, SDRB_OP_OR, false>(g, gx, gy); }
+    } else {
+        if (is_and) { if (swap) launch_visit<int32_t, SDRB_OP_AND, true>(g, gx, gy); else launch_visit<int32_t, SDRB_OP_AND, false>(g, gx, gy); }
+        else { if (swap) launch_visit<int32_t, SDRB_OP_OR, true>(g, gx, gy); else launch_visit<int32_t, SDRB_OP_OR, false>(g, gx, gy); }
+    }
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
 }
 
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,

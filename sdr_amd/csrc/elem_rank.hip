@@ -115,7 +115,9 @@ __global__ __launch_bounds__(kBlock) void k_build_rank_tables(const uint32_t* __
 // block therefore stages its (at most kQueryChunk) rows of A once -- rank tables, ids and payloads --
 // in LDS; a wave stages its row of B per row, keeps the first 64 elements of it in registers, and
 // fetches the output offsets of all its pairs with one load per row of B.
-template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+// VISIT: instead of elements, the positions a visitor would be called with -- out_ids gets the position in
+// `this` and out_data (as uint32) the position in `arg`, 0xFFFFFFFF for the absent side of a single.
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false>
 __global__ __launch_bounds__(kBlock) void k_elem_rank(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_data,
     uint32_t na, const RankEntry* __restrict__ a_tab, const uint32_t* __restrict__ b_off,
@@ -235,8 +237,13 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
                     pos += rg - (matched + prefix_of(hit, n_hit));   // arg-only elements below x
                 }
                 if (keep) {
-                    out_ids[base + pos] = (int32_t)x;
-                    if constexpr (THIS_UNIT) out_data[base + pos] = v;
+                    if constexpr (VISIT) {
+                        out_ids[base + pos] = (int32_t)(k0 + lane);
+                        reinterpret_cast<uint32_t*>(out_data)[base + pos] = hit ? rg : 0xFFFFFFFFu;
+                    } else {
+                        out_ids[base + pos] = (int32_t)x;
+                        if constexpr (THIS_UNIT) out_data[base + pos] = v;
+                    }
                 }
                 emitted += n_keep;
                 matched += n_hit;
@@ -267,8 +274,13 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
                     uint32_t pos = rt + singles + prefix_of(single, n_single);
                     if constexpr (OP == SDRB_OP_XOR) pos -= dropped + prefix_of(drop, n_drop);
                     if (single) {
-                        out_ids[base + pos] = (int32_t)x;
-                        if constexpr (THIS_UNIT) out_data[base + pos] = ARG_UNIT ? v : 1.0f;
+                        if constexpr (VISIT) {
+                            out_ids[base + pos] = -1;
+                            reinterpret_cast<uint32_t*>(out_data)[base + pos] = k0 + lane;
+                        } else {
+                            out_ids[base + pos] = (int32_t)x;
+                            if constexpr (THIS_UNIT) out_data[base + pos] = ARG_UNIT ? v : 1.0f;
+                        }
                     }
                     singles += n_single;
                     dropped += n_drop;
@@ -286,20 +298,27 @@ struct Args {
     int32_t* out_ids;
     float* out_data;
     uint32_t nw, qc, cap_a, cap_b, rows_per_wave;
+    bool visit;
     dim3 grid;
     size_t lds;
     hipStream_t stream;
 };
 
-template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false>
 void launch(const Args& g) {
-    hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
+    hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
                        g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets, g.b->d_ids, g.b->d_data,
                        (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc, g.cap_a, g.cap_b, g.rows_per_wave);
 }
 
 template <int OP, bool SWAP>
 void launch_kinds(const Args& g) {
+    if constexpr (OP == SDRB_OP_AND || OP == SDRB_OP_OR) {
+        if (g.visit) {   // positions only: payloads play no part
+            launch<OP, SWAP, false, false, true>(g);
+            return;
+        }
+    }
     const bool au = g.a->data_kind == SDRB_DATA_UNIT, bu = g.b->data_kind == SDRB_DATA_UNIT;
     if (au && bu) launch<OP, SWAP, true, true>(g);
     else if (au) launch<OP, SWAP, true, false>(g);
@@ -357,7 +376,7 @@ bool elem_rank_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 }
 
 int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
-                     int32_t* out_ids, float* out_data, hipStream_t stream) {
+                     int32_t* out_ids, float* out_data, hipStream_t stream, bool visit) {
     const Shape shape = shape_for(a, b);
     const uint32_t nw = shape.nw;
     RankEntry* a_tab = static_cast<RankEntry*>(workspace(b->device, 9, (size_t)a->n_rows * nw * sizeof(RankEntry)));
@@ -373,6 +392,7 @@ int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
     g.out_off = out_offsets;
     g.out_ids = out_ids;
     g.out_data = out_data;
+    g.visit = visit;
     g.nw = nw;
     g.qc = shape.qc;
     g.cap_a = shape.cap_a;

@@ -99,6 +99,10 @@ int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
                      const uint32_t* out_offsets, void* out_ids, float* out_data, bool rowwise,
                      hipStream_t stream);
 
+// visitor positions of andv (SDRB_OP_AND) / orv (SDRB_OP_OR) by the per-pair merge, any id width
+int launch_elem_visit(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
+                      uint32_t* this_pos, uint32_t* arg_pos, bool rowwise, hipStream_t stream);
+
 // elem_bitmap.hip ------------------------------------------------------------------
 // Dense-bitset fill for id-only results (`this` side EmptyData, declared width <= 4096).
 bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);
@@ -109,8 +113,10 @@ int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool sw
 // Wave-per-pair fill from rank tables (bitset + popcount prefix per row): any payload kinds, all four
 // ops, declared width <= 32768.
 bool elem_rank_applicable(const sdrb_batch* a, const sdrb_batch* b);
+// visit: write visitor positions instead of elements (op AND / OR; out_ids = this positions, out_data =
+// arg positions as uint32)
 int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
-                     int32_t* out_ids, float* out_data, hipStream_t stream);
+                     int32_t* out_ids, float* out_data, hipStream_t stream, bool visit = false);
 
 // size_popcount.hip ------------------------------------------------------------------
 // Dense-bitset popcount size ops (id-only results, declared width <= 2048).

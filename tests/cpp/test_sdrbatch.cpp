@@ -243,6 +243,44 @@ int run_queries(std::mt19937& rng, const char* name) {
     return 0;
 }
 
+// batched visitors: the records equal, call by call, what the reference's andv / orv hand to visitors
+// (positions = iterator - begin()), for vector rows with payloads on one side
+int run_visitors(std::mt19937& rng, const char* name) {
+    using U = SDRElem<int, UnitData>;
+    using E = SDRElem<>;
+    auto qs = make_rows<SDR<U>>(rng, 17, 300, 80);
+    auto ds = make_rows<SDR<E>>(rng, 120, 300, 80);
+    auto q = sdr_amd::SDRBatch::pack(qs.begin(), qs.end(), 0, 300);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 300);
+    auto av = q.andv(d).to_host(), ov = q.orv(d).to_host();
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            const size_t p = i * ds.size() + j;
+            uint32_t k = av.offsets[p];
+            bool ok = true;
+            qs[i].andv(ds[j], [&](SDR<U>::iterator tp, SDR<E>::iterator ap) {
+                ok = ok && k < av.offsets[p + 1] && av.this_pos[k] == (uint32_t)(tp - qs[i].begin()) &&
+                     av.arg_pos[k] == (uint32_t)(ap - ds[j].begin());
+                ++k;
+            });
+            REQUIRE(ok && k == av.offsets[p + 1]);
+            k = ov.offsets[p];
+            auto rec = [&](uint32_t tp, uint32_t ap) {
+                ok = ok && k < ov.offsets[p + 1] && ov.this_pos[k] == tp && ov.arg_pos[k] == ap;
+                ++k;
+            };
+            qs[i].orv(ds[j],
+                      [&](SDR<U>::iterator tp) { rec((uint32_t)(tp - qs[i].begin()), SDRB_POS_NONE); },
+                      [&](SDR<E>::iterator ap) { rec(SDRB_POS_NONE, (uint32_t)(ap - ds[j].begin())); },
+                      [&](SDR<U>::iterator tp, SDR<E>::iterator ap) {
+                          rec((uint32_t)(tp - qs[i].begin()), (uint32_t)(ap - ds[j].begin()));
+                      });
+            REQUIRE(ok && k == ov.offsets[p + 1]);
+        }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
 // operator sugar (SDR.hpp:431-460) on batches equals the reference's operators on every pair / row
 int run_operators(std::mt19937& rng, const char* name) {
     using U = SDRElem<int, UnitData>;
@@ -343,6 +381,7 @@ int main() {
         if (run_inplace<SDR<U>, SDR<E>>(rng, "in-place unit x empty")) return 1;
         if (run_queries(rng, "range/point/transpose")) return 1;
         if (run_operators(rng, "operator sugar")) return 1;
+        if (run_visitors(rng, "andv / orv visitors")) return 1;
         if (run_file<SDR<E>>(rng, "file_empty")) return 1;
         if (run_file<SDR<U>>(rng, "file_unit")) return 1;
         if (run_file<SDR<AE>>(rng, "file_arith")) return 1;

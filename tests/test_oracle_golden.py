@@ -156,6 +156,27 @@ def test_readme_known_answers():
     assert ids == [0] and data == [0.5]
 
 
+def test_visitor_call_sequences_vs_golden(golden):
+    """andv / orv (SDR.hpp:958-997, 1099-1166): the restatement calls its visitors with the positions the
+    reference's own visitors received."""
+    g = golden("visit.npz")
+    t = Batch(*util.fuzz_universe(64, None))
+    for which, name in ((0, "andv"), (1, "orv")):
+        off, tp, ap = oracle.port().visit(which, t, t)
+        assert np.array_equal(off, g[f"fuzz_{name}_off"])
+        assert np.array_equal(tp, g[f"fuzz_{name}_this"]) and np.array_equal(ap, g[f"fuzz_{name}_arg"])
+    q, d = Batch(g["q_off"], g["q_ids"]), Batch(g["d_off"], g["d_ids"])
+    for which, name in ((0, "andv"), (1, "orv")):
+        off, tp, ap = oracle.port().visit(which, q, d)
+        assert np.array_equal(np.diff(off).astype(np.uint32), g[f"ragged_{name}_len"])
+        assert np.array_equal(util.visit_digests(off, tp, ap), g[f"ragged_{name}_digest"])
+    # andv reports each common id once, with positions that point at equal ids
+    off, tp, ap = oracle.port().visit(0, q, d)
+    pair = np.repeat(np.arange(q.n * d.n), np.diff(off).astype(np.int64))
+    qi, dj = pair // d.n, pair % d.n
+    assert np.array_equal(q.ids[q.off[qi].astype(np.int64) + tp], d.ids[d.off[dj].astype(np.int64) + ap])
+
+
 def test_reference_unit_test_known_answers():
     # src/test.cpp:172-184 -- andv visits two pairs
     t = Batch.from_rows([[1, 2, 3]])

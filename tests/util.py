@@ -114,6 +114,20 @@ def pair_digests(off: np.ndarray, ids: np.ndarray, data: np.ndarray | None) -> n
     return ((out >> np.uint64(32)) ^ (out & np.uint64(0xFFFFFFFF))).astype(np.uint32)
 
 
+def visit_digests(off: np.ndarray, this_pos: np.ndarray, arg_pos: np.ndarray) -> np.ndarray:
+    """One order-sensitive 64-bit digest per pair of its visitor records (this position, arg position)."""
+    off = np.asarray(off, dtype=np.uint64)
+    if off.size <= 1:
+        return np.zeros(0, np.uint64)
+    lens = np.diff(off).astype(np.int64)
+    k = np.arange(this_pos.size, dtype=np.uint64) - np.repeat(off[:-1], lens)
+    with np.errstate(over="ignore"):
+        term = (k + np.uint64(1)) * (this_pos.astype(np.uint64) * np.uint64(0x9E3779B1)
+                                     + arg_pos.astype(np.uint64) * np.uint64(0x85EBCA77) + np.uint64(1))
+        csum = np.concatenate([np.zeros(1, np.uint64), np.cumsum(term, dtype=np.uint64)])
+        return csum[off[1:].astype(np.int64)] - csum[off[:-1].astype(np.int64)]
+
+
 def ragged_rows(rng: np.random.Generator, n_rows: int, width: int, max_len: int, with_data=False,
                 lo: int = 0):
     """Random ragged batch: row lengths uniform in [0, max_len], ids in [lo, lo+width)."""

@@ -20,6 +20,8 @@ Fixtures
                     sizes + element-op lengths and digests.
   mini_16k_328.npz  4 queries x 512 rows, width 16384 / 328 active, UnitData x UnitData.
   inplace.npz       andi/ori/xori/rmi on a 5-id universe incl. the aliased a.op(a) cases.
+  visit.npz         the calls of the reference's andv / orv visitors (positions in this and arg) on the
+                    6-id fuzz universe (64x64 pairs, complete) and on ragged rows (lengths and digests).
 """
 from __future__ import annotations
 
@@ -266,6 +268,24 @@ def gen_transpose():
     np.savez_compressed(os.path.join(OUT, "transpose.npz"), **out)
 
 
+def gen_visit():
+    """What andv / orv call their visitors with (SDR.hpp:186-194,268-269), taken from the reference's own
+    visitors on std::vector rows; the restatement must produce the same call sequences."""
+    out = {}
+    t = oracle.Batch(*util.fuzz_universe(64, None))
+    for which, name in ((0, "andv"), (1, "orv")):
+        off, tp, ap = both("visit", which, t, t)
+        out.update({f"fuzz_{name}_off": off, f"fuzz_{name}_this": tp, f"fuzz_{name}_arg": ap})
+    rng = np.random.default_rng(FUZZ_SEED + 21)
+    q = oracle.Batch(*util.ragged_rows(rng, 40, 3000, 150, False))
+    d = oracle.Batch(*util.ragged_rows(rng, 300, 3000, 150, False))
+    out.update({"q_off": q.off, "q_ids": q.ids, "d_off": d.off, "d_ids": d.ids})
+    for which, name in ((0, "andv"), (1, "orv")):
+        off, tp, ap = both("visit", which, q, d)
+        out.update({f"ragged_{name}_len": np.diff(off).astype(np.uint32), f"ragged_{name}_digest": util.visit_digests(off, tp, ap)})
+    np.savez_compressed(os.path.join(OUT, "visit.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not oracle.have_reference():
@@ -282,6 +302,10 @@ def main():
     if sys.argv[1:] == ["inner"]:       # only the fixture of the sparse dot products
         gen_inner()
         return
+    if sys.argv[1:] == ["visit"]:
+        gen_visit()
+        return
+    gen_visit()
     gen_inner()
     gen_queries()
     gen_transpose()
