@@ -54,8 +54,10 @@ extern "C" {
 #define SDRB_DATA_EMPTY 0 /* DataTypes/EmptyData.hpp:18-92: zero-size payload */
 #define SDRB_DATA_UNIT 1  /* DataTypes/UnitData.hpp:11-140: float in [0,1] */
 #define SDRB_DATA_ARITH 2 /* DataTypes/ArithData.hpp:11-107 with arith_t = float; payloads must be finite here
-                             (the reference allows any float); only sdrb_inner and the payload-blind
-                             sdrb_allpairs_topk take such batches */
+                             (the reference allows any float).  Besides sdrb_inner such batches take the set
+                             algebra with ArithData or EmptyData partners: and = product, or = sum, rm =
+                             difference, every payload relevant (ArithData.hpp:22-83); there is no xor
+                             (ArithData.hpp:110-114) and no mixing with UnitData */
 
 /* flags of the binary operations */
 #define SDRB_FLAG_SWAP 1u           /* result(i,j) = B_j.op(A_i) instead of A_i.op(B_j) */

@@ -19,7 +19,7 @@ REF_SO = os.path.join(_HERE, "_ref", "libsdr_ref.so")
 REF_DBG_SO = os.path.join(_HERE, "_ref", "libsdr_ref_dbg.so")
 REF_FUZZ = os.path.join(_HERE, "_ref", "fuzz_sdr")
 
-EMPTY, UNIT = 0, 1
+EMPTY, UNIT, ARITH = 0, 1, 2
 AND, OR, XOR, RM = 0, 1, 2, 3
 OP_NAMES = {AND: "and", OR: "or", XOR: "xor", RM: "rm"}
 
@@ -33,13 +33,14 @@ def build(ref: bool = True) -> None:
 
 
 class Batch:
-    """Host CSR pack: offsets uint64[n+1], ids int32, data float32 or None."""
+    """Host CSR pack: offsets uint64[n+1], ids int32, data float32 or None.  Payloads are UnitData unless
+    ``arith`` says they are ArithData<float>."""
 
-    def __init__(self, offsets, ids, data=None):
+    def __init__(self, offsets, ids, data=None, arith: bool = False):
         self.off = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.ids = np.ascontiguousarray(ids, dtype=np.int32)
         self.data = None if data is None else np.ascontiguousarray(data, dtype=np.float32)
-        self.kind = EMPTY if data is None else UNIT
+        self.kind = EMPTY if data is None else (ARITH if arith else UNIT)
         self.n = self.off.size - 1
         assert int(self.off[-1]) == self.ids.size
         assert self.data is None or self.data.size == self.ids.size
@@ -219,7 +220,7 @@ class _Impl:
         off = np.zeros(t.n * a.n + 1, dtype=np.uint64)
         total = fn(*head, *t.args(), *a.args(), off.ctypes.data_as(_vp), None, None)
         ids = np.zeros(total, dtype=np.int32)
-        data = np.zeros(total, dtype=np.float32) if t.kind == UNIT else None
+        data = np.zeros(total, dtype=np.float32) if t.kind != EMPTY else None
         fn(*head, *t.args(), *a.args(), off.ctypes.data_as(_vp), ids.ctypes.data_as(_vp),
            data.ctypes.data_as(_vp) if data is not None else None)
         return off, ids, data

@@ -28,10 +28,12 @@ namespace {
 
 using EmptyElem = SDRElem<int, EmptyData>;
 using UnitElem = SDRElem<int, UnitData>;
+using ArithElem = SDRElem<int, ArithData<float>>;
 using EmptySDR = SDR<EmptyElem>;
 using UnitSDR = SDR<UnitElem>;
+using ArithSDR = SDR<ArithElem>;
 
-enum { K_EMPTY = 0, K_UNIT = 1 };
+enum { K_EMPTY = 0, K_UNIT = 1, K_ARITH = 2 };
 enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_RM = 3 };
 
 template <typename S>
@@ -41,6 +43,8 @@ std::vector<S> build(const uint64_t* off, const int32_t* ids, const float* data,
         for (uint64_t k = off[r]; k < off[r + 1]; ++k) {
             if constexpr (std::is_same_v<S, UnitSDR>) {
                 rows[r].push_back(UnitElem(ids[k], UnitData(data[k])));
+            } else if constexpr (std::is_same_v<S, ArithSDR>) {
+                rows[r].push_back(ArithElem(ids[k], ArithData<float>(data[k])));
             } else {
                 rows[r].push_back(EmptyElem(ids[k]));
             }
@@ -49,12 +53,19 @@ std::vector<S> build(const uint64_t* off, const int32_t* ids, const float* data,
     return rows;
 }
 
+// ArithData defines no xor (ArithData.hpp:110-114): those calls do not compile in the reference, so they are
+// kept out of the instantiations that involve it (callers never ask for them).
+template <typename A, typename B>
+constexpr bool has_xor = !std::is_same_v<A, ArithSDR> && !std::is_same_v<B, ArithSDR>;
+
 template <typename A, typename B>
 size_t size_op(int op, const A& a, const B& b) {
     switch (op) {
     case OP_AND: return a.ands(b);
     case OP_OR: return a.ors(b);
-    case OP_XOR: return a.xors(b);
+    case OP_XOR:
+        if constexpr (has_xor<A, B>) return a.xors(b);
+        else return 0;
     default: return a.rms(b);
     }
 }
@@ -64,7 +75,9 @@ A elem_op(int op, const A& a, const B& b) {
     switch (op) {
     case OP_AND: return a.ande(b);
     case OP_OR: return a.ore(b);
-    case OP_XOR: return a.xore(b);
+    case OP_XOR:
+        if constexpr (has_xor<A, B>) return a.xore(b);
+        else return A();
     default: return a.rme(b);
     }
 }
@@ -74,15 +87,17 @@ void inplace_op(int op, A& a, const B& b) {
     switch (op) {
     case OP_AND: a.andi(b); break;
     case OP_OR: a.ori(b); break;
-    case OP_XOR: a.xori(b); break;
+    case OP_XOR:
+        if constexpr (has_xor<A, B>) a.xori(b);
+        break;
     default: a.rmi(b); break;
     }
 }
 
 template <typename S>
 float payload(const typename S::value_type& e) {
-    if constexpr (std::is_same_v<S, UnitSDR>) return e.data().value();
-    else return 0.0f;
+    if constexpr (std::is_same_v<S, EmptySDR>) return 0.0f;
+    else return e.data().value();
 }
 
 template <typename A, typename B>
@@ -160,6 +175,9 @@ double time_size(int op, const std::vector<A>& t, const std::vector<B>& a, int r
         if ((tk) == K_EMPTY && (ak) == K_EMPTY) { CALL(EmptySDR, EmptySDR); }         \
         else if ((tk) == K_EMPTY && (ak) == K_UNIT) { CALL(EmptySDR, UnitSDR); }      \
         else if ((tk) == K_UNIT && (ak) == K_EMPTY) { CALL(UnitSDR, EmptySDR); }      \
+        else if ((tk) == K_ARITH && (ak) == K_ARITH) { CALL(ArithSDR, ArithSDR); }    \
+        else if ((tk) == K_ARITH && (ak) == K_EMPTY) { CALL(ArithSDR, EmptySDR); }    \
+        else if ((tk) == K_EMPTY && (ak) == K_ARITH) { CALL(EmptySDR, ArithSDR); }    \
         else { CALL(UnitSDR, UnitSDR); }                                              \
     } while (0)
 
@@ -188,7 +206,7 @@ uint64_t rsdr_batch_elem_op(int op, int inplace,
 #define CALL(A, B)                                          \
     auto t = build<A>(t_off, t_ids, t_data, t_n);           \
     auto a = build<B>(a_off, a_ids, a_data, a_n);           \
-    total = batch_elem(op, inplace != 0, t, a, out_off, out_ids, t_kind == K_UNIT ? out_data : nullptr)
+    total = batch_elem(op, inplace != 0, t, a, out_off, out_ids, t_kind != K_EMPTY ? out_data : nullptr)
     DISPATCH(t_kind, a_kind, CALL);
 #undef CALL
     return total;

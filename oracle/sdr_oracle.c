@@ -20,20 +20,21 @@
  * the double literal. */
 static int unit_relevant(float v) { return (double)v >= 0.1; }
 
-/* relevant(): EmptyData.hpp:29-32 (always), UnitData.hpp:22-24. */
-static int relevant(int kind, float v) { return kind == OSDR_EMPTY ? 1 : unit_relevant(v); }
+/* relevant(): EmptyData.hpp:29-32 (always), UnitData.hpp:22-24, ArithData.hpp:22-24 (always). */
+static int relevant(int kind, float v) { return kind == OSDR_UNIT ? unit_relevant(v) : 1; }
 
-/* rm_relevant(): EmptyData.hpp:34-37 (never), UnitData.hpp:26-28. */
-static int rm_relevant(int kind, float v) { return kind == OSDR_EMPTY ? 0 : unit_relevant(v); }
+/* rm_relevant(): EmptyData.hpp:34-37 (never), UnitData.hpp:26-28, ArithData.hpp:26-28 (= relevant: always). */
+static int rm_relevant(int kind, float v) { return kind == OSDR_EMPTY ? 0 : kind == OSDR_UNIT ? unit_relevant(v) : 1; }
 
-/* andi: UnitData.hpp:37-46 (multiply; identity against EmptyData). */
+/* andi: UnitData.hpp:37-46, ArithData.hpp:37-43 (multiply; identity against EmptyData). */
 static float data_and(int tk, int ak, float tv, float av) {
-    if (tk == OSDR_UNIT && ak == OSDR_UNIT) return tv * av;
+    if (tk != OSDR_EMPTY && ak != OSDR_EMPTY) return tv * av;
     return tv;
 }
-/* ori: UnitData.hpp:60-69. */
+/* ori: UnitData.hpp:60-69 (the larger), ArithData.hpp:57-63 (the sum). */
 static float data_or(int tk, int ak, float tv, float av) {
     if (tk == OSDR_UNIT && ak == OSDR_UNIT) return tv > av ? tv : av;
+    if (tk == OSDR_ARITH && ak == OSDR_ARITH) return tv + av;
     return tv;
 }
 /* xori: UnitData.hpp:83-92 (std::abs on float). */
@@ -41,22 +42,25 @@ static float data_xor(int tk, int ak, float tv, float av) {
     if (tk == OSDR_UNIT && ak == OSDR_UNIT) return fabsf(tv - av);
     return tv;
 }
-/* rmi: UnitData.hpp:106-115 (`1 - o.value()` is a float subtraction, then a multiply). */
+/* rmi: UnitData.hpp:106-115 (`1 - o.value()` is a float subtraction, then a multiply);
+ * ArithData.hpp:77-83 (the difference).  ArithData has no xor (ArithData.hpp:110-114). */
 static float data_rm(int tk, int ak, float tv, float av) {
     if (tk == OSDR_UNIT && ak == OSDR_UNIT) {
         float one_minus = 1 - av;
         return tv * one_minus;
     }
+    if (tk == OSDR_ARITH && ak == OSDR_ARITH) return tv - av;
     return tv;
 }
-/* Converting ctor SDRElem.hpp:29-30: UnitData(EmptyData) is 1 (UnitData.hpp:13-14);
- * EmptyData swallows anything (EmptyData.hpp:25-27). */
+/* Converting ctor SDRElem.hpp:29-30: UnitData(EmptyData) is 1 (UnitData.hpp:13-14), ArithData(EmptyData)
+ * is 0 (ArithData.hpp:15-16); EmptyData swallows anything (EmptyData.hpp:25-27). */
 static float data_convert(int tk, int ak, float av) {
     if (tk == OSDR_UNIT) return ak == OSDR_UNIT ? av : 1.0f;
+    if (tk == OSDR_ARITH) return ak == OSDR_ARITH ? av : 0.0f;
     return 0.0f;
 }
 
-static float vdata(const osdr_view* s, size_t i) { return s->kind == OSDR_UNIT ? s->data[i] : 0.0f; }
+static float vdata(const osdr_view* s, size_t i) { return s->kind != OSDR_EMPTY ? s->data[i] : 0.0f; }
 
 /* ------------------------------------------------------------------ merges */
 
@@ -243,7 +247,7 @@ static void rme_both_visit(void* p, size_t tp, size_t ap) {
 
 size_t osdr_elem_op(int op, const osdr_view* t, const osdr_view* a,
                     int32_t* out_ids, float* out_data) {
-    elem_ctx c = {t, a, out_ids, t->kind == OSDR_UNIT ? out_data : NULL, 0, 0};
+    elem_ctx c = {t, a, out_ids, t->kind != OSDR_EMPTY ? out_data : NULL, 0, 0};
     switch (op) {
     case OSDR_AND: /* SDR.hpp:999-1025 */
         osdr_andv(t->ids, t->n, a->ids, a->n, ande_visit, &c);
@@ -280,14 +284,14 @@ typedef struct {
 static void andi_visit(void* p, size_t tp, size_t ap) {
     inplace_ctx* c = (inplace_ctx*)p;
     float d = 0.0f;
-    if (c->kind == OSDR_UNIT) {
+    if (c->kind != OSDR_EMPTY) {
         d = data_and(c->kind, c->a->kind, c->data[tp], vdata(c->a, ap));
         c->data[tp] = d; /* andi mutates this's payload in place (:1033) */
     }
     if (relevant(c->kind, d)) {
         if (c->pos != tp) {
             c->ids[c->pos] = c->ids[tp];
-            if (c->kind == OSDR_UNIT) c->data[c->pos] = d;
+            if (c->kind != OSDR_EMPTY) c->data[c->pos] = d;
         }
         ++c->pos;
     }
@@ -297,18 +301,18 @@ static void rmi_visit(void* p, size_t tp, size_t ap) {
     inplace_ctx* c = (inplace_ctx*)p;
     while (c->this_fill != tp) {
         c->ids[c->pos] = c->ids[c->this_fill];
-        if (c->kind == OSDR_UNIT) c->data[c->pos] = c->data[c->this_fill];
+        if (c->kind != OSDR_EMPTY) c->data[c->pos] = c->data[c->this_fill];
         ++c->pos;
         ++c->this_fill;
     }
     float d = 0.0f;
-    if (c->kind == OSDR_UNIT) {
+    if (c->kind != OSDR_EMPTY) {
         d = data_rm(c->kind, c->a->kind, c->data[tp], vdata(c->a, ap));
         c->data[tp] = d; /* rmi_combine mutates in place (:1439-1443) */
     }
     if (rm_relevant(c->kind, d)) {
         c->ids[c->pos] = c->ids[tp];
-        if (c->kind == OSDR_UNIT) c->data[c->pos] = d;
+        if (c->kind != OSDR_EMPTY) c->data[c->pos] = d;
         ++c->pos;
     }
     ++c->this_fill;
@@ -325,7 +329,7 @@ size_t osdr_inplace_op(int op, int32_t* t_ids, float* t_data, size_t t_n, int t_
         osdr_andv(t_ids, t_n, a->ids, a->n, rmi_visit, &c);
         while (c.this_fill != t_n) {
             c.ids[c.pos] = c.ids[c.this_fill];
-            if (c.kind == OSDR_UNIT) c.data[c.pos] = c.data[c.this_fill];
+            if (c.kind != OSDR_EMPTY) c.data[c.pos] = c.data[c.this_fill];
             ++c.pos;
             ++c.this_fill;
         }
@@ -338,7 +342,7 @@ size_t osdr_inplace_op(int op, int32_t* t_ids, float* t_data, size_t t_n, int t_
         osdr_view t = {t_ids, t_data, t_n, t_kind};
         size_t n = osdr_elem_op(op, &t, a, r_ids, r_data);
         memcpy(t_ids, r_ids, n * sizeof(int32_t));
-        if (t_kind == OSDR_UNIT) memcpy(t_data, r_data, n * sizeof(float));
+        if (t_kind != OSDR_EMPTY) memcpy(t_data, r_data, n * sizeof(float));
         free(r_ids);
         free(r_data);
         return n;
@@ -353,7 +357,7 @@ static osdr_view row_view(const uint64_t* off, const int32_t* ids, const float* 
                           uint64_t r) {
     osdr_view v;
     v.ids = ids + off[r];
-    v.data = (kind == OSDR_UNIT && data) ? data + off[r] : NULL;
+    v.data = (kind != OSDR_EMPTY && data) ? data + off[r] : NULL;
     v.n = (size_t)(off[r + 1] - off[r]);
     v.kind = kind;
     return v;
@@ -508,7 +512,7 @@ uint64_t osdr_batch_elem_op(int op,
             size_t n = osdr_elem_op(op, &t, &a, tmp_ids, tmp_data);
             if (out_ids) {
                 memcpy(out_ids + total, tmp_ids, n * sizeof(int32_t));
-                if (out_data && t_kind == OSDR_UNIT) memcpy(out_data + total, tmp_data, n * sizeof(float));
+                if (out_data && t_kind != OSDR_EMPTY) memcpy(out_data + total, tmp_data, n * sizeof(float));
             }
             total += n;
         }

@@ -26,7 +26,8 @@ extern "C" {
 
 /* payload kinds */
 enum { OSDR_EMPTY = 0, /* DataTypes/EmptyData.hpp:18-92  */
-       OSDR_UNIT = 1   /* DataTypes/UnitData.hpp:11-140  */ };
+       OSDR_UNIT = 1,  /* DataTypes/UnitData.hpp:11-140  */
+       OSDR_ARITH = 2  /* DataTypes/ArithData.hpp:11-107 with arith_t = float; no xor ops */ };
 
 /* set operations */
 enum { OSDR_AND = 0, OSDR_OR = 1, OSDR_XOR = 2, OSDR_RM = 3 };

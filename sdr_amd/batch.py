@@ -387,7 +387,7 @@ class SDRBatch:
         # buffers keep at least one element so an empty result still has a valid pointer
         ids_buf = torch.empty(max(n, 1), dtype=torch.int64 if self.id_bits == 64 else torch.int32, device=dev)
         this_kind = other.data_kind if swap else self.data_kind
-        data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if this_kind == DATA_UNIT else None
+        data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if this_kind != DATA_EMPTY else None
         fill = self._lib.sdrb_elem_op_fill64 if self.id_bits == 64 else self._lib.sdrb_elem_op_fill
         check(fill(self._h, other._h, op, flags, offsets.data_ptr(),
                                           ids_buf.data_ptr(),

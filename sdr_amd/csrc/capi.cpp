@@ -160,13 +160,51 @@ int check_ids32(const sdrb_batch* a, const sdrb_batch* b, const char* what) {
     return SDRB_OK;
 }
 
-// the set algebra is implemented for EmptyData and UnitData payloads
-int check_set_algebra_kinds(const sdrb_batch* a, const sdrb_batch* b) {
-    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) {
-        set_error("ArithData batches are taken by sdrb_inner only");
+// Which payload pairings the set algebra takes: EmptyData and UnitData in any mix (UnitData.hpp:43-46),
+// ArithData<float> with itself or with EmptyData (ArithData.hpp:37-83); ArithData defines no xor (:110-114).
+int check_set_algebra_kinds(const sdrb_batch* a, const sdrb_batch* b, int op) {
+    const bool arith = a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH;
+    if (arith && (a->data_kind == SDRB_DATA_UNIT || b->data_kind == SDRB_DATA_UNIT)) {
+        set_error("ArithData and UnitData batches do not combine");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (arith && op == SDRB_OP_XOR) {
+        set_error("ArithData has no xor operations (ArithData.hpp:110-114)");
         return SDRB_ERR_UNSUPPORTED;
     }
     return SDRB_OK;
+}
+
+// A batch seen without its payloads.  Derived data built through the view belongs to the batch it views,
+// so it is handed back.
+struct IdView {
+    sdrb_batch v;
+    const sdrb_batch* src;
+    explicit IdView(const sdrb_batch* s) : v(*s), src(s) {
+        v.data_kind = SDRB_DATA_EMPTY;
+        v.d_data = nullptr;
+        v.owns_storage = false;
+    }
+    ~IdView() {
+        sdrb_batch* m = const_cast<sdrb_batch*>(src);
+        m->d_bitplanes = v.d_bitplanes;
+        m->d_dense8 = v.d_dense8;
+        m->dense_chunks = v.dense_chunks;
+    }
+};
+
+// out(i, j) = length of the `this` row: rms of an ArithData `this`, whose matches all stay (ArithData.hpp:26-28,85-88)
+__global__ __launch_bounds__(256) void k_fill_this_len(const uint32_t* __restrict__ a_off, const uint32_t* __restrict__ b_off,
+                                                       uint64_t na, uint64_t nb, uint32_t swap, uint32_t rowwise,
+                                                       uint32_t* __restrict__ out, uint64_t ld_out) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nb) return;
+    const uint32_t lb = b_off[j + 1] - b_off[j];
+    if (rowwise) {
+        out[j] = swap ? lb : a_off[j + 1] - a_off[j];
+        return;
+    }
+    for (uint64_t i = blockIdx.y; i < na; i += gridDim.y) out[i * ld_out + j] = swap ? lb : a_off[i + 1] - a_off[i];
 }
 
 }  // namespace
@@ -606,7 +644,7 @@ int sdrb_batch_destroy(sdrb_batch* batch) {
 int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                  uint64_t ld_out, void* stream) {
     int rc = check_pair(a, b, op);
-    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
     if (rc != SDRB_OK) return rc;
     const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
     if (rowwise && a->n_rows != b->n_rows) {
@@ -621,6 +659,26 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_INVALID_ARG;
     }
     const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) {
+        // ArithData payloads are always relevant (ArithData.hpp:22-28), so sizes depend on ids alone: ands and ors
+        // are those of the id sets, rms of an ArithData `this` keeps every element, an EmptyData `this` is ids only.
+        const sdrb_batch* self = swap ? b : a;
+        if (op == SDRB_OP_RM && self->data_kind == SDRB_DATA_ARITH) {
+            DeviceGuard guard(b->device);
+            if (!guard.ok) {
+                set_error("hipSetDevice(%d) failed", b->device);
+                return SDRB_ERR_HIP;
+            }
+            const uint32_t gy = rowwise ? 1u : (uint32_t)(a->n_rows < 1024 ? a->n_rows : 1024);
+            hipLaunchKernelGGL(k_fill_this_len, dim3((uint32_t)((b->n_rows + 255) / 256), gy), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), a->d_offsets, b->d_offsets, a->n_rows, b->n_rows,
+                               swap ? 1u : 0u, rowwise ? 1u : 0u, out, ld_out);
+            SDRB_HIP(hipGetLastError());
+            return SDRB_OK;
+        }
+        IdView va(a), vb(b);
+        return sdrb_size_op(&va.v, &vb.v, op, flags, out, ld_out, stream);
+    }
     const bool can_bitslice = a->id_bits == 32 && id_only(a, b, op, swap) && bitslice_applicable(a, b);
     if ((flags & SDRB_FLAG_FORCE_BITSLICE) && !can_bitslice) {
         set_error("bit-sliced kernel requested but not applicable to these batches/op");
@@ -849,7 +907,7 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                        uint32_t* out_offsets, uint64_t* total, void* stream) {
     int rc = check_pair(a, b, op);
-    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
     if (rc != SDRB_OK) return rc;
     if (!out_offsets || !total) {
         set_error("sdrb_elem_op_count: null output");
@@ -909,7 +967,7 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         rc = SDRB_ERR_INVALID_ARG;
     }
     int32_t* out_ids = static_cast<int32_t*>(out_ids_any);
-    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
     if (rc != SDRB_OK) return rc;
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
     const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
@@ -919,9 +977,28 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         return SDRB_ERR_INVALID_ARG;
     }
     const sdrb_batch* self = swap ? b : a;
-    if (!out_offsets || !out_ids || (self->data_kind == SDRB_DATA_UNIT && !out_data)) {
-        set_error("sdrb_elem_op_fill: null output (UnitData results need out_data)");
+    if (!out_offsets || !out_ids || (has_payload(self) && !out_data)) {
+        set_error("sdrb_elem_op_fill: null output (results with payloads need out_data)");
         return SDRB_ERR_INVALID_ARG;
+    }
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) {
+        if (self->data_kind == SDRB_DATA_EMPTY) {   // results are ids only: the argument's payloads play no part
+            IdView va(a), vb(b);
+            return elem_op_fill_any(&va.v, &vb.v, op, flags, out_offsets, out_ids_any, want_bits, nullptr, stream);
+        }
+        DeviceGuard arith_guard(b->device);
+        if (!arith_guard.ok) {
+            set_error("hipSetDevice(%d) failed", b->device);
+            return SDRB_ERR_HIP;
+        }
+        hipStream_t as = static_cast<hipStream_t>(stream);
+        if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && elem_rank_applicable(a, b))
+            return launch_elem_rank(a, b, op, swap, out_offsets, out_ids, out_data, as);
+        if (flags & SDRB_FLAG_FORCE_RANK) {
+            set_error("the rank-table fill does not apply to these batches");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_elem_fill(a, b, op, swap, out_offsets, out_ids_any, out_data, rowwise, as);
     }
     DeviceGuard guard(b->device);
     if (!guard.ok) {
@@ -960,24 +1037,6 @@ int sdrb_elem_op_fill64(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
 }
 
 namespace {
-// A batch seen without its payloads (what the visitors' positions depend on).  Derived data built through
-// the view belongs to the batch it views, so it is handed back.
-struct IdView {
-    sdrb_batch v;
-    const sdrb_batch* src;
-    explicit IdView(const sdrb_batch* s) : v(*s), src(s) {
-        v.data_kind = SDRB_DATA_EMPTY;
-        v.d_data = nullptr;
-        v.owns_storage = false;
-    }
-    ~IdView() {
-        sdrb_batch* m = const_cast<sdrb_batch*>(src);
-        m->d_bitplanes = v.d_bitplanes;
-        m->d_dense8 = v.d_dense8;
-        m->dense_chunks = v.dense_chunks;
-    }
-};
-
 int check_visit(const sdrb_batch* a, const sdrb_batch* b, int which) {
     if (!a || !b) {
         set_error("null batch handle");

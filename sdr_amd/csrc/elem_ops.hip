@@ -85,7 +85,7 @@ int scan_level(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t stream) {
 // VISIT (ids only, ande / ore): instead of elements, the positions a visitor of andv / orv would be called
 // with -- out_ids (as uint32) gets the position in `this`, out_data (as uint32) the position in `arg`,
 // 0xFFFFFFFF for the absent side of a single.
-template <typename ID, int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false>
+template <typename ID, int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false, bool ARITH = false>
 __global__ __launch_bounds__(kBlock) void k_elem_fill(
     const uint32_t* __restrict__ a_off, const ID* __restrict__ a_ids,
     const float* __restrict__ a_data, uint64_t na, const uint32_t* __restrict__ b_off,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
             if constexpr (!SWAP) {
                 if constexpr (KEEP_THIS_ONLY) emit(ai[pa], va);
             } else {
-                if constexpr (KEEP_ARG_ONLY) emit(ai[pa], ARG_UNIT ? va : 1.0f);
+                if constexpr (KEEP_ARG_ONLY) emit(ai[pa], converted_arg<ARG_UNIT, ARITH>(va));
             }
         };
         auto only_b = [&](uint32_t pb) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
             if constexpr (SWAP) {
                 if constexpr (KEEP_THIS_ONLY) emit(bi[pb], vb);
             } else {
-                if constexpr (KEEP_ARG_ONLY) emit(bi[pb], ARG_UNIT ? vb : 1.0f);
+                if constexpr (KEEP_ARG_ONLY) emit(bi[pb], converted_arg<ARG_UNIT, ARITH>(vb));
             }
         };
         uint32_t pa = 0, pb = 0;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(kBlock) void k_elem_fill(
                 } else {
                     const float va = A_UNIT ? ad[pa] : 0.0f;
                     const float vb = B_UNIT ? bd[pb] : 0.0f;
-                    const float d = SWAP ? match_data<OP, ARG_UNIT>(vb, va) : match_data<OP, ARG_UNIT>(va, vb);
-                    if (match_kept<OP, THIS_UNIT>(d)) emit(x, d);
+                    const float d = SWAP ? match_data<OP, ARG_UNIT, ARITH>(vb, va) : match_data<OP, ARG_UNIT, ARITH>(va, vb);
+                    if (match_kept<OP, THIS_UNIT, ARITH>(d)) emit(x, d);
                 }
                 ++pa;
                 ++pb;
@@ -186,6 +186,30 @@ struct FillArgs {
     bool rowwise;
     hipStream_t stream;
 };
+
+// ArithData<float> payloads (32-bit ids; `this` carries the payloads -- an EmptyData `this` is served as ids only)
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
+void launch_arith(const FillArgs& g) {
+    const uint32_t gx = (uint32_t)((g.b->n_rows + kBlock - 1) / kBlock);
+    const uint32_t gy = g.rowwise ? 1u : (uint32_t)(g.a->n_rows < 65535 ? g.a->n_rows : 65535);
+    hipLaunchKernelGGL((k_elem_fill<int32_t, OP, SWAP, A_UNIT, B_UNIT, false, true>), dim3(gx, gy), dim3(kBlock), 0, g.stream,
+                       g.a->d_offsets, g.a->d_ids, g.a->d_data, g.a->n_rows, g.b->d_offsets, g.b->d_ids,
+                       g.b->d_data, g.b->n_rows, g.out_off, static_cast<int32_t*>(g.out_ids), g.out_data,
+                       g.rowwise ? 1u : 0u);
+}
+
+template <int OP>
+void launch_arith_kinds(const FillArgs& g, bool swap) {
+    const bool ap = g.a->data_kind != SDRB_DATA_EMPTY, bp = g.b->data_kind != SDRB_DATA_EMPTY;
+    if (ap && bp) {
+        if (swap) launch_arith<OP, true, true, true>(g);
+        else launch_arith<OP, false, true, true>(g);
+    } else if (ap) {
+        launch_arith<OP, false, true, false>(g);   // this = A (payloads), arg = B (ids only)
+    } else {
+        launch_arith<OP, true, false, true>(g);    // this = B (payloads), arg = A (ids only)
+    }
+}
 
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
 void launch(const FillArgs& g) {
@@ -268,6 +292,16 @@ int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
                      const uint32_t* out_offsets, void* out_ids, float* out_data, bool rowwise,
                      hipStream_t stream) {
     FillArgs g{a, b, out_offsets, out_ids, out_data, rowwise, stream};
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) {   // caller: `this` is the ArithData side
+        switch (op) {
+        case SDRB_OP_AND: launch_arith_kinds<SDRB_OP_AND>(g, swap); break;
+        case SDRB_OP_OR: launch_arith_kinds<SDRB_OP_OR>(g, swap); break;
+        case SDRB_OP_RM: launch_arith_kinds<SDRB_OP_RM>(g, swap); break;
+        default: set_error("ArithData has no xor (ArithData.hpp:110-114)"); return SDRB_ERR_UNSUPPORTED;
+        }
+        SDRB_HIP(hipGetLastError());
+        return SDRB_OK;
+    }
     switch (op) {
     case SDRB_OP_AND: launch_swap<SDRB_OP_AND>(g, swap); break;
     case SDRB_OP_OR: launch_swap<SDRB_OP_OR>(g, swap); break;

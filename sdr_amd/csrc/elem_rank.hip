@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_build_rank_tables(const uint32_t* __
 // fetches the output offsets of all its pairs with one load per row of B.
 // VISIT: instead of elements, the positions a visitor would be called with -- out_ids gets the position in
 // `this` and out_data (as uint32) the position in `arg`, 0xFFFFFFFF for the absent side of a single.
-template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false>
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false, bool ARITH = false>
 __global__ __launch_bounds__(kBlock) void k_elem_rank(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_data,
     uint32_t na, const RankEntry* __restrict__ a_tab, const uint32_t* __restrict__ b_off,
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
                 bool keep = live && OP != SDRB_OP_AND;
                 if (hit) {
                     const float gv = ARG_UNIT ? lds_load(&g_val[rg]) : 0.0f;   // a present id's rank is its position
-                    v = match_data<OP, ARG_UNIT>(v, gv);
-                    keep = match_kept<OP, THIS_UNIT>(v);
+                    v = match_data<OP, ARG_UNIT, ARITH>(v, gv);
+                    keep = match_kept<OP, THIS_UNIT, ARITH>(v);
                 }
                 uint32_t n_keep, n_hit = 0;
                 uint32_t pos = emitted + prefix_of(keep, n_keep);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
                             reinterpret_cast<uint32_t*>(out_data)[base + pos] = k0 + lane;
                         } else {
                             out_ids[base + pos] = (int32_t)x;
-                            if constexpr (THIS_UNIT) out_data[base + pos] = ARG_UNIT ? v : 1.0f;
+                            if constexpr (THIS_UNIT) out_data[base + pos] = converted_arg<ARG_UNIT, ARITH>(v);
                         }
                     }
                     singles += n_single;
@@ -304,9 +304,9 @@ struct Args {
     hipStream_t stream;
 };
 
-template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false>
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false, bool ARITH = false>
 void launch(const Args& g) {
-    hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
+    hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
                        g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets, g.b->d_ids, g.b->d_data,
                        (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc, g.cap_a, g.cap_b, g.rows_per_wave);
 }
@@ -316,6 +316,16 @@ void launch_kinds(const Args& g) {
     if constexpr (OP == SDRB_OP_AND || OP == SDRB_OP_OR) {
         if (g.visit) {   // positions only: payloads play no part
             launch<OP, SWAP, false, false, true>(g);
+            return;
+        }
+    }
+    if constexpr (OP != SDRB_OP_XOR) {
+        if (g.a->data_kind == SDRB_DATA_ARITH || g.b->data_kind == SDRB_DATA_ARITH) {
+            // ArithData<float>: `this` is the side with payloads (the caller serves an EmptyData `this` as ids only)
+            const bool ap = g.a->data_kind != SDRB_DATA_EMPTY, bp = g.b->data_kind != SDRB_DATA_EMPTY;
+            if (ap && bp) launch<OP, SWAP, true, true, false, true>(g);
+            else if (ap) { if constexpr (!SWAP) launch<OP, false, true, false, false, true>(g); }
+            else { if constexpr (SWAP) launch<OP, true, false, true, false, true>(g); }
             return;
         }
     }

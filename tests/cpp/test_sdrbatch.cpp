@@ -243,6 +243,31 @@ int run_queries(std::mt19937& rng, const char* name) {
     return 0;
 }
 
+// the set algebra on ArithData<float> rows (and = product, or = sum, rm = difference; no xor): every pair
+// against the reference's own calls
+template <typename A, typename B>
+int run_arith(std::mt19937& rng, const char* name) {
+    auto qs = make_rows<A>(rng, 19, 200, 40);
+    auto ds = make_rows<B>(rng, 150, 200, 40);
+    auto q = sdr_amd::SDRBatch::pack(qs.begin(), qs.end(), 0, 200);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 200);
+    auto c_and = q.ands(d).to_host(), c_or = q.ors(d).to_host(), c_rm = q.rms(d).to_host();
+    auto h_and = q.ande(d).to_host(), h_or = q.ore(d).to_host(), h_rm = q.rme(d).to_host();
+    using R = SDR<typename A::value_type, std::vector<typename A::value_type>>;
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            const size_t k = i * ds.size() + j;
+            REQUIRE(c_and[k] == qs[i].ands(ds[j]));
+            REQUIRE(c_or[k] == qs[i].ors(ds[j]));
+            REQUIRE(c_rm[k] == qs[i].rms(ds[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_and, ds.size(), i, j) == qs[i].ande(ds[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_or, ds.size(), i, j) == qs[i].ore(ds[j]));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_rm, ds.size(), i, j) == qs[i].rme(ds[j]));
+        }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
 // batched visitors: the records equal, call by call, what the reference's andv / orv hand to visitors
 // (positions = iterator - begin()), for vector rows with payloads on one side
 int run_visitors(std::mt19937& rng, const char* name) {
@@ -382,6 +407,9 @@ int main() {
         if (run_queries(rng, "range/point/transpose")) return 1;
         if (run_operators(rng, "operator sugar")) return 1;
         if (run_visitors(rng, "andv / orv visitors")) return 1;
+        if (run_arith<SDR<AE>, SDR<AE>>(rng, "arith x arith")) return 1;
+        if (run_arith<SDR<AE>, SDR<E>>(rng, "arith x empty")) return 1;
+        if (run_arith<SDR<E>, SDR<AE>>(rng, "empty x arith")) return 1;
         if (run_file<SDR<E>>(rng, "file_empty")) return 1;
         if (run_file<SDR<U>>(rng, "file_unit")) return 1;
         if (run_file<SDR<AE>>(rng, "file_arith")) return 1;

@@ -74,4 +74,6 @@ def test_inner_special_values_and_rejections():
     with pytest.raises(SdrbError):
         arith.inner(unit)          # UnitData argument: not an ArithData product
     with pytest.raises(SdrbError):
-        arith.ands(arith)          # the set algebra is not defined here for ArithData batches
+        arith.xors(arith)          # ArithData has no xor (ArithData.hpp:110-114)
+    with pytest.raises(SdrbError):
+        arith.ands(unit)           # ArithData and UnitData do not combine

@@ -156,6 +156,20 @@ def test_readme_known_answers():
     assert ids == [0] and data == [0.5]
 
 
+def test_arith_set_algebra_vs_golden(golden):
+    """ArithData<float> rows (ArithData.hpp:37-88): the restatement equals the reference's outputs."""
+    g = golden("arith.npz")
+    for tag, (ta, aa) in {"AA": (True, True), "AE": (True, False), "EA": (False, True)}.items():
+        t = Batch(g[f"{tag}_t_off"], g[f"{tag}_t_ids"], g[f"{tag}_t_data"] if ta else None, arith=ta)
+        a = Batch(g[f"{tag}_a_off"], g[f"{tag}_a_ids"], g[f"{tag}_a_data"] if aa else None, arith=aa)
+        for op in (oracle.AND, oracle.OR, oracle.RM):
+            assert np.array_equal(oracle.port().size_op(op, t, a), g[f"{tag}_size{op}"])
+            off, ids, data = oracle.port().elem_op(op, t, a)
+            assert np.array_equal(np.diff(off).astype(np.uint32), g[f"{tag}_len{op}"])
+            assert np.array_equal(util.pair_digests(off, ids, data), g[f"{tag}_digest{op}"])
+            assert np.array_equal(np.diff(off).reshape(t.n, a.n), g[f"{tag}_size{op}"])   # ands == ande.size() ...
+
+
 def test_visitor_call_sequences_vs_golden(golden):
     """andv / orv (SDR.hpp:958-997, 1099-1166): the restatement calls its visitors with the positions the
     reference's own visitors received."""

@@ -20,6 +20,7 @@ Fixtures
                     sizes + element-op lengths and digests.
   mini_16k_328.npz  4 queries x 512 rows, width 16384 / 328 active, UnitData x UnitData.
   inplace.npz       andi/ori/xori/rmi on a 5-id universe incl. the aliased a.op(a) cases.
+  arith.npz         and / or / rm on ArithData<float> rows (sizes, element-op lengths and digests).
   visit.npz         the calls of the reference's andv / orv visitors (positions in this and arg) on the
                     6-id fuzz universe (64x64 pairs, complete) and on ragged rows (lengths and digests).
 """
@@ -268,6 +269,29 @@ def gen_transpose():
     np.savez_compressed(os.path.join(OUT, "transpose.npz"), **out)
 
 
+def gen_arith():
+    """The set algebra on ArithData<float> rows (ArithData.hpp:37-88): and = product, or = sum, rm = difference,
+    every payload relevant, no xor; pairings arith x arith, arith x empty, empty x arith."""
+    rng = np.random.default_rng(FUZZ_SEED + 31)
+    out = {}
+    for tag, (ta, aa) in {"AA": (True, True), "AE": (True, False), "EA": (False, True)}.items():
+        t_off, t_ids, t_data = util.arith_rows(rng, 24, 300, 60)
+        a_off, a_ids, a_data = util.arith_rows(rng, 90, 300, 60)
+        t = oracle.Batch(t_off, t_ids, t_data if ta else None, arith=ta)
+        a = oracle.Batch(a_off, a_ids, a_data if aa else None, arith=aa)
+        out.update({f"{tag}_t_off": t.off, f"{tag}_t_ids": t.ids, f"{tag}_a_off": a.off, f"{tag}_a_ids": a.ids})
+        if ta:
+            out[f"{tag}_t_data"] = t.data
+        if aa:
+            out[f"{tag}_a_data"] = a.data
+        for op in (oracle.AND, oracle.OR, oracle.RM):
+            out[f"{tag}_size{op}"] = both("size_op", op, t, a)
+            off, ids, data = both("elem_op", op, t, a)
+            out[f"{tag}_len{op}"] = np.diff(off).astype(np.uint32)
+            out[f"{tag}_digest{op}"] = util.pair_digests(off, ids, data)
+    np.savez_compressed(os.path.join(OUT, "arith.npz"), **out)
+
+
 def gen_visit():
     """What andv / orv call their visitors with (SDR.hpp:186-194,268-269), taken from the reference's own
     visitors on std::vector rows; the restatement must produce the same call sequences."""
@@ -305,6 +329,10 @@ def main():
     if sys.argv[1:] == ["visit"]:
         gen_visit()
         return
+    if sys.argv[1:] == ["arith"]:
+        gen_arith()
+        return
+    gen_arith()
     gen_visit()
     gen_inner()
     gen_queries()
