@@ -129,32 +129,37 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap(
     }
 }
 
-// Two pairs per wave for widths <= 2048: a half-wave of 32 lanes holds the 2048 bits of a pair as
-// 64-bit words, so every wave instruction of the scan / enumerate / copy-out sequence serves two
-// pairs.  The wave's work items are the pairs (i, j) of its tile in j-major order; item p goes to
-// half p & 1 (two rows of A against the same row of B, or -- with a single row of A -- two rows of B).
-// a_bits is the same memory as for the 32-bit kernel (word k of 64 bits = ids 64 k .. 64 k + 63).
-__device__ __forceinline__ uint32_t half_inclusive_scan(uint32_t v) {   // prefix sums inside each 32-lane half
+// Several pairs per wave for widths <= 2048: LP lanes (32 or 16) hold the 2048 bits of a pair as 64-bit
+// words (one or two per lane), so every wave instruction of the scan / enumerate / copy-out sequence
+// serves 64 / LP pairs.  The wave's work items are the pairs (i, j) of its tile in j-major order; item
+// p goes to lane group p % (64 / LP) (rows of A against the same row of B, or -- with a single row of
+// A -- several rows of B).  a_bits is the same memory as for the 32-bit kernel (word k of 64 bits =
+// ids 64 k .. 64 k + 63).
+template <int LP>
+__device__ __forceinline__ uint32_t group_inclusive_scan(uint32_t v) {   // prefix sums inside each group of LP lanes
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    if constexpr (LP == 32)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
     return v;
 }
 
-constexpr int kHalfStage = 128;   // ids a half-wave can stage in LDS for one coalesced copy-out
+constexpr int kGroupStage = 128;   // ids a lane group can stage in LDS for one coalesced copy-out
 
-template <int OP, bool SWAP>
+template <int OP, bool SWAP, int LP>
 __global__ __launch_bounds__(kBlock) void k_elem_bitmap_pairs(
     const unsigned long long* __restrict__ a_bits, uint32_t na, const uint32_t* __restrict__ b_off,
     const int32_t* __restrict__ b_ids, uint32_t nb, const uint32_t* __restrict__ out_off,
     int32_t* __restrict__ out_ids, uint32_t rows_per_wave) {
     using u64 = unsigned long long;
-    __shared__ u64 lds_bits[kWaves][2][32];
-    __shared__ int32_t lds_stage[kWaves][2][kHalfStage];
+    constexpr int PPW = 64 / LP;   // pairs per wave turn
+    constexpr int WPL = 32 / LP;   // 64-bit words per lane
+    __shared__ u64 lds_bits[kWaves][PPW][32];
+    __shared__ int32_t lds_stage[kWaves][PPW][kGroupStage];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t half = lane >> 5, hl = lane & 31;
+    const uint32_t grp = lane / LP, gl = lane % LP;
     const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * rows_per_wave;
     const uint64_t j_end = j_begin + rows_per_wave < nb ? j_begin + rows_per_wave : nb;
     const uint32_t i_begin = blockIdx.y * kQueryChunk;
@@ -163,63 +168,205 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap_pairs(
     const uint32_t ni = i_end - i_begin;
     const uint32_t nj = (uint32_t)(j_end - j_begin);
 
-    u64* my_bits = lds_bits[wave][half];
-    int32_t* my_stage = lds_stage[wave][half];
-    uint64_t held_j = ~0ull;   // the row of B whose bitset this half currently holds
-    u64 rbits = 0;
-    uint32_t jj = half / ni, ii = half % ni;   // this half's item, advanced by two items per turn
-    for (uint32_t turn = 0, turns = (nj * ni + 1) / 2; turn < turns; ++turn) {
+    u64* my_bits = lds_bits[wave][grp];
+    int32_t* my_stage = lds_stage[wave][grp];
+    uint64_t held_j = ~0ull;   // the row of B whose bitset this group currently holds
+    u64 rbits[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) rbits[w] = 0;
+    uint32_t jj = grp / ni, ii = grp % ni;   // this group's item, advanced by PPW items per turn
+    for (uint32_t turn = 0, turns = (nj * ni + PPW - 1) / PPW; turn < turns; ++turn) {
         const bool valid = jj < nj;
         const uint64_t j = j_begin + (valid ? jj : 0);
         const uint32_t i = i_begin + (valid ? ii : 0);
-        ii += 2;
+        ii += PPW;
         while (ii >= ni) { ii -= ni; ++jj; }
-        // (re)build the half's bitset of row j: zero the words, OR the ids in, read my word back
+        // (re)build the group's bitset of row j: zero the words, OR the ids in, read my words back
         if (__builtin_amdgcn_ballot_w64(valid && j != held_j) != 0) {
             if (valid && j != held_j) {
                 const uint32_t beg = b_off[j], len = b_off[j + 1] - beg;
-                lds_store(&my_bits[hl], (u64)0);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) lds_store(&my_bits[gl * WPL + w], (u64)0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                for (uint32_t k = hl; k < len; k += 32) {
+                for (uint32_t k = gl; k < len; k += LP) {
                     const uint32_t id = (uint32_t)b_ids[beg + k];
                     __hip_atomic_fetch_or(&my_bits[id >> 6], (u64)1 << (id & 63), __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                rbits = lds_load(&my_bits[hl]);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) rbits[w] = lds_load(&my_bits[gl * WPL + w]);
                 held_j = j;
             }
         }
-        u64 res = 0;
-        if (valid) {
-            const u64 qbits = a_bits[(uint64_t)i * 32 + hl];
-            const u64 self = SWAP ? rbits : qbits, arg = SWAP ? qbits : rbits;
-            if constexpr (OP == SDRB_OP_AND) res = self & arg;
-            else if constexpr (OP == SDRB_OP_OR) res = self | arg;
-            else if constexpr (OP == SDRB_OP_XOR) res = self ^ arg;
-            else res = self & ~arg;
+        u64 res[WPL];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+            res[w] = 0;
+            if (valid) {
+                const u64 qbits = a_bits[(uint64_t)i * 32 + gl * WPL + w];
+                const u64 self = SWAP ? rbits[w] : qbits, arg = SWAP ? qbits : rbits[w];
+                if constexpr (OP == SDRB_OP_AND) res[w] = self & arg;
+                else if constexpr (OP == SDRB_OP_OR) res[w] = self | arg;
+                else if constexpr (OP == SDRB_OP_XOR) res[w] = self ^ arg;
+                else res[w] = self & ~arg;
+            }
+            cnt += (uint32_t)__builtin_popcountll(res[w]);
         }
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(res);
-        const uint32_t incl = half_inclusive_scan(cnt);
-        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
-        const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if ((t0 | t1) == 0) continue;
-        const uint32_t total = half ? t1 : t0;
+        const uint32_t incl = group_inclusive_scan<LP>(cnt);
+        // the group's total sits in its last lane
+        const uint32_t total = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane | (LP - 1)) << 2), (int)incl);
+        if (__builtin_amdgcn_ballot_w64(total != 0) == 0) continue;
         const uint32_t base = valid ? out_off[(uint64_t)i * nb + j] : 0u;
         uint32_t pos = incl - cnt;
-        if (t0 <= (uint32_t)kHalfStage && t1 <= (uint32_t)kHalfStage) {
-            while (res) {
-                lds_store(&my_stage[pos++], (int32_t)(hl * 64 + (uint32_t)__builtin_ctzll(res)));
-                res &= res - 1;
+        if (__builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0) {
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                u64 r = res[w];
+                while (r) {
+                    lds_store(&my_stage[pos++], (int32_t)((gl * WPL + w) * 64 + (uint32_t)__builtin_ctzll(r)));
+                    r &= r - 1;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            for (uint32_t t = hl; t < total; t += 32) out_ids[base + t] = lds_load(&my_stage[t]);
+            for (uint32_t t = gl; t < total; t += LP) out_ids[base + t] = lds_load(&my_stage[t]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         } else {
             pos += base;
-            while (res) {
-                out_ids[pos++] = (int32_t)(hl * 64 + (uint32_t)__builtin_ctzll(res));
-                res &= res - 1;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                u64 r = res[w];
+                while (r) {
+                    out_ids[pos++] = (int32_t)((gl * WPL + w) * 64 + (uint32_t)__builtin_ctzll(r));
+                    r &= r - 1;
+                }
+            }
+        }
+    }
+}
+
+// The same kernel with everything a wave reads staged in LDS before its first store.  On this hardware a
+// wait for a load also waits for every store issued before it, so a loop that loads (a row of B, a bitset
+// of A, an output offset) and stores in every turn runs at the latency of a store.  Here the block copies
+// the bitsets of its rows of A, and each wave the ids of its (at most kMaxRows) rows of B and the output
+// offsets of its pairs, into LDS up front; the turns then touch global memory only to store.
+// Needs rows of B of at most kRowCap ids (the launcher checks).
+constexpr int kMaxRows = 16;
+constexpr int kRowCap = 64;
+
+template <int OP, bool SWAP, int LP>
+__global__ __launch_bounds__(kBlock) void k_elem_bitmap_staged(
+    const unsigned long long* __restrict__ a_bits, uint32_t na, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, uint32_t nb, const uint32_t* __restrict__ out_off,
+    int32_t* __restrict__ out_ids, uint32_t rows_per_wave) {
+    using u64 = unsigned long long;
+    constexpr int PPW = 64 / LP;   // pairs per wave turn
+    constexpr int WPL = 32 / LP;   // 64-bit words per lane
+    __shared__ u64 s_abits[kQueryChunk * 32];
+    __shared__ u64 s_bits[kWaves][PPW][32];
+    // ids are below 2048 here: 16 bits each keep the block's LDS at 24 KiB (six blocks per compute unit)
+    __shared__ uint16_t s_stage[kWaves][PPW][kGroupStage];
+    __shared__ uint16_t s_rows[kWaves][kMaxRows][kRowCap];
+    __shared__ uint32_t s_base[kWaves][kMaxRows * kQueryChunk];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t grp = lane / LP, gl = lane % LP;
+    const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * rows_per_wave;   // rows_per_wave <= kMaxRows
+    const uint64_t j_end = j_begin + rows_per_wave < nb ? j_begin + rows_per_wave : nb;
+    const uint32_t i_begin = blockIdx.y * kQueryChunk;
+    const uint32_t ni = (i_begin + kQueryChunk < na ? i_begin + kQueryChunk : na) - i_begin;
+    const uint32_t nj = j_begin < j_end ? (uint32_t)(j_end - j_begin) : 0u;
+
+    for (uint32_t idx = threadIdx.x; idx < ni * 32; idx += kBlock) s_abits[idx] = a_bits[(uint64_t)i_begin * 32 + idx];
+    // offsets of the wave's rows of B, one per lane (lanes 0..nj); then all rows at once
+    const uint32_t b_off_reg = nj ? b_off[j_begin + (lane <= nj ? lane : nj)] : 0u;
+    int32_t row_id[kMaxRows];
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r) {
+        const uint32_t beg = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r + 1 <= (int)nj ? r + 1 : (int)nj);
+        row_id[r] = ((uint32_t)r < nj && lane < end - beg) ? b_ids[beg + lane] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r) s_rows[wave][r][lane] = (uint16_t)row_id[r];
+    for (uint32_t idx = lane; idx < nj * ni; idx += 64)
+        s_base[wave][idx] = out_off[(uint64_t)(i_begin + idx % ni) * nb + j_begin + idx / ni];
+    __syncthreads();
+    if (nj == 0) return;
+
+    u64* my_bits = s_bits[wave][grp];
+    uint16_t* my_stage = s_stage[wave][grp];
+    uint32_t held_jj = ~0u;   // the row of B whose bitset this group currently holds
+    u64 rbits[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) rbits[w] = 0;
+    uint32_t jj = grp / ni, ii = grp % ni;   // this group's item, advanced by PPW items per turn
+    for (uint32_t turn = 0, turns = (nj * ni + PPW - 1) / PPW; turn < turns; ++turn) {
+        const bool valid = jj < nj;
+        const uint32_t cj = valid ? jj : 0u, ci = valid ? ii : 0u;
+        ii += PPW;
+        while (ii >= ni) { ii -= ni; ++jj; }
+        // (re)build the group's bitset of row cj: zero the words, OR the ids in, read my words back
+        if (__builtin_amdgcn_ballot_w64(valid && cj != held_jj) != 0) {
+            if (valid && cj != held_jj) {
+                // this lane's copy of the offsets is not its group's: fetch the row's bounds by index
+                const uint32_t len = (uint32_t)__shfl((int)b_off_reg, (int)cj + 1) - (uint32_t)__shfl((int)b_off_reg, (int)cj);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) lds_store(&my_bits[gl * WPL + w], (u64)0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                for (uint32_t k = gl; k < len; k += LP) {
+                    const uint32_t id = (uint32_t)lds_load(&s_rows[wave][cj][k]);
+                    __hip_atomic_fetch_or(&my_bits[id >> 6], (u64)1 << (id & 63), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) rbits[w] = lds_load(&my_bits[gl * WPL + w]);
+                held_jj = cj;
+            }
+        }
+        u64 res[WPL];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+            res[w] = 0;
+            if (valid) {
+                const u64 qbits = s_abits[ci * 32 + gl * WPL + w];
+                const u64 self = SWAP ? rbits[w] : qbits, arg = SWAP ? qbits : rbits[w];
+                if constexpr (OP == SDRB_OP_AND) res[w] = self & arg;
+                else if constexpr (OP == SDRB_OP_OR) res[w] = self | arg;
+                else if constexpr (OP == SDRB_OP_XOR) res[w] = self ^ arg;
+                else res[w] = self & ~arg;
+            }
+            cnt += (uint32_t)__builtin_popcountll(res[w]);
+        }
+        const uint32_t incl = group_inclusive_scan<LP>(cnt);
+        // the group's total sits in its last lane
+        const uint32_t total = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane | (LP - 1)) << 2), (int)incl);
+        if (__builtin_amdgcn_ballot_w64(total != 0) == 0) continue;
+        const uint32_t base = lds_load(&s_base[wave][cj * ni + ci]);
+        uint32_t pos = incl - cnt;
+        if (__builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0) {
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                u64 r = res[w];
+                while (r) {
+                    lds_store(&my_stage[pos++], (uint16_t)((gl * WPL + w) * 64 + (uint32_t)__builtin_ctzll(r)));
+                    r &= r - 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t t = gl; t < total; t += LP) out_ids[base + t] = (int32_t)lds_load(&my_stage[t]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+            pos += base;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                u64 r = res[w];
+                while (r) {
+                    out_ids[pos++] = (int32_t)((gl * WPL + w) * 64 + (uint32_t)__builtin_ctzll(r));
+                    r &= r - 1;
+                }
             }
         }
     }
@@ -238,10 +385,17 @@ struct Args {
 
 template <typename WORD, int OP, bool SWAP>
 void launch(const Args& g) {
-    if constexpr (sizeof(WORD) == 4) {   // widths <= 2048: two pairs per wave on 64-bit words
-        hipLaunchKernelGGL((k_elem_bitmap_pairs<OP, SWAP>), g.grid, dim3(kBlock), 0, g.stream,
-                           static_cast<const unsigned long long*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
-                           g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
+    if constexpr (sizeof(WORD) == 4) {   // widths <= 2048: several pairs per wave on 64-bit words
+        // 16 lanes per pair (four pairs per wave) measured ahead of 32 (config 3 ore: 2.85 vs 2.96 ms at 16 queries)
+        // staging pays once a wave has a few rows of A per row of B to amortise it over
+        if (g.b->max_row_len <= (uint32_t)kRowCap && g.rows_per_wave <= (uint32_t)kMaxRows && g.a->n_rows >= 4)
+            hipLaunchKernelGGL((k_elem_bitmap_staged<OP, SWAP, 16>), g.grid, dim3(kBlock), 0, g.stream,
+                               static_cast<const unsigned long long*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
+                               g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
+        else
+            hipLaunchKernelGGL((k_elem_bitmap_pairs<OP, SWAP, 16>), g.grid, dim3(kBlock), 0, g.stream,
+                               static_cast<const unsigned long long*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
+                               g.b->d_ids, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.rows_per_wave);
     } else {
         hipLaunchKernelGGL((k_elem_bitmap<WORD, OP, SWAP>), g.grid, dim3(kBlock), 0, g.stream,
                            static_cast<const WORD*>(g.a_bits), (uint32_t)g.a->n_rows, g.b->d_offsets,
