@@ -220,7 +220,31 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap_pairs(
         if (__builtin_amdgcn_ballot_w64(total != 0) == 0) continue;
         const uint32_t base = valid ? out_off[(uint64_t)i * nb + j] : 0u;
         uint32_t pos = incl - cnt;
-        if (__builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0) {
+        // one row of A: the groups' pairs (i, j), (i, j+1), ... are neighbours in the output and leave the
+        // wave as one coalesced run
+        if (ni == 1 && __builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0) {
+            uint32_t run_before = 0, run_total = 0;
+#pragma unroll
+            for (int g = 0; g < PPW; ++g) {
+                const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)total, g * LP);
+                if ((uint32_t)g < grp) run_before += tg;
+                run_total += tg;
+            }
+            pos += run_before;
+            int32_t* wave_stage = lds_stage[wave][0];
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                u64 r = res[w];
+                while (r) {
+                    lds_store(&wave_stage[pos++], (int32_t)((gl * WPL + w) * 64 + (uint32_t)__builtin_ctzll(r)));
+                    r &= r - 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t run_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            for (uint32_t t = lane; t < run_total; t += 64) out_ids[run_base + t] = lds_load(&wave_stage[t]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else if (__builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0) {
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
                 u64 r = res[w];
@@ -300,12 +324,15 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap_staged(
     u64 rbits[WPL];
 #pragma unroll
     for (int w = 0; w < WPL; ++w) rbits[w] = 0;
-    uint32_t jj = grp / ni, ii = grp % ni;   // this group's item, advanced by PPW items per turn
+    // Items in i-major order: the groups of a turn take consecutive rows of B against the same row of A, so
+    // their results are neighbours in the output and leave the wave as one coalesced run.
+    uint32_t ii = grp / nj, jj = grp % nj;   // this group's item, advanced by PPW items per turn
+    uint16_t* wave_stage = s_stage[wave][0];   // the groups' stages, back to back
     for (uint32_t turn = 0, turns = (nj * ni + PPW - 1) / PPW; turn < turns; ++turn) {
-        const bool valid = jj < nj;
+        const bool valid = ii < ni;
         const uint32_t cj = valid ? jj : 0u, ci = valid ? ii : 0u;
-        ii += PPW;
-        while (ii >= ni) { ii -= ni; ++jj; }
+        jj += PPW;
+        while (jj >= nj) { jj -= nj; ++ii; }
         // (re)build the group's bitset of row cj: zero the words, OR the ids in, read my words back
         if (__builtin_amdgcn_ballot_w64(valid && cj != held_jj) != 0) {
             if (valid && cj != held_jj) {
@@ -346,7 +373,33 @@ __global__ __launch_bounds__(kBlock) void k_elem_bitmap_staged(
         if (__builtin_amdgcn_ballot_w64(total != 0) == 0) continue;
         const uint32_t base = lds_load(&s_base[wave][cj * ni + ci]);
         uint32_t pos = incl - cnt;
-        if (__builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0) {
+        const bool fits = __builtin_amdgcn_ballot_w64(total > (uint32_t)kGroupStage) == 0;
+        // all groups on the same row of A: their results are contiguous in the output (pairs (i, j), (i, j+1), ...)
+        const uint32_t first_i = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
+        const bool together = __builtin_amdgcn_ballot_w64(valid && ci != first_i) == 0;
+        if (fits && together) {
+            // totals of the groups (idle groups have none) -> where each group's ids start in the wave's run
+            uint32_t run_before = 0, run_total = 0;
+#pragma unroll
+            for (int g = 0; g < PPW; ++g) {
+                const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)total, g * LP);
+                if ((uint32_t)g < grp) run_before += tg;
+                run_total += tg;
+            }
+            pos += run_before;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                u64 r = res[w];
+                while (r) {
+                    lds_store(&wave_stage[pos++], (uint16_t)((gl * WPL + w) * 64 + (uint32_t)__builtin_ctzll(r)));
+                    r &= r - 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t run_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // group 0's pair comes first
+            for (uint32_t t = lane; t < run_total; t += 64) out_ids[run_base + t] = (int32_t)lds_load(&wave_stage[t]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else if (fits) {
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
                 u64 r = res[w];

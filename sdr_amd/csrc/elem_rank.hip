@@ -290,6 +290,227 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
     }
 }
 
+// ---------------------------------------------------------------- short rows: four pairs per wave
+// lanes of my group (LP consecutive lanes) below mine whose flag is set, and the group's total
+template <int LP>
+__device__ __forceinline__ uint32_t group_prefix(bool flag, uint32_t lane, uint32_t& total) {
+    const u64 m = __builtin_amdgcn_ballot_w64(flag);
+    const uint32_t gm = (uint32_t)(m >> (lane & ~(uint32_t)(LP - 1))) & ((1u << LP) - 1u);
+    total = (uint32_t)__builtin_popcount(gm);
+    return (uint32_t)__builtin_popcount(gm & ((1u << (lane & (LP - 1))) - 1u));
+}
+
+constexpr int kShortCap = 64;    // longest row the short-row kernel takes (either batch)
+constexpr int kShortRows = 8;    // rows of B a wave stages and works through
+
+// Rows of at most kShortCap elements on both sides: groups of 16 lanes work on four rows of A against the
+// same row of B, so that 40-element rows still fill the wave, and EVERYTHING a wave reads -- its kShortRows
+// rows of B and the output offsets of all its pairs, besides the block's rows of A -- is in LDS before its
+// first store: between stores the wave never waits for a load (a wait for a load would also wait for every
+// store issued before it).
+// NCH: 16-element chunks per row (rows hold at most NCH * 16 elements).
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT, bool ARITH, int NCH>
+__global__ __launch_bounds__(kBlock) void k_elem_rank_short(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_data,
+    uint32_t na, const RankEntry* __restrict__ a_tab, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint32_t nb,
+    const uint32_t* __restrict__ out_off, int32_t* __restrict__ out_ids, float* __restrict__ out_data,
+    uint32_t nw, uint32_t qc, uint32_t rows_per_wave) {
+    constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
+    constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
+    constexpr bool UNION = OP == SDRB_OP_OR || OP == SDRB_OP_XOR;
+    constexpr bool DROP_BY_VALUE = OP == SDRB_OP_XOR && THIS_UNIT;
+    constexpr int LP = 16, GROUPS = 64 / LP, CAP = kShortCap, ROWS = kShortRows;
+    // LDS: tables of the waves' current rows of B | tables of the block's rows of A | rows of A: ids, payloads |
+    //      the waves' rows of B: ids, payloads | output offsets of the waves' pairs
+    extern __shared__ RankEntry smem[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t grp = lane / LP, gl = lane % LP;
+    RankEntry* btab = smem + (size_t)wave * nw;
+    RankEntry* atab_all = smem + (size_t)kWaves * nw;
+    uint32_t* a_ids_all = reinterpret_cast<uint32_t*>(atab_all + (size_t)qc * nw);
+    float* a_val_all = reinterpret_cast<float*>(a_ids_all + (size_t)qc * CAP);
+    uint32_t* b_ids_all = reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * CAP) + (size_t)wave * ROWS * CAP;
+    float* b_val_all = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * CAP) +
+                                                (size_t)kWaves * ROWS * CAP) + (size_t)wave * ROWS * CAP;
+    uint32_t* base_all = reinterpret_cast<uint32_t*>(reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * CAP) +
+                                                     (size_t)2 * kWaves * ROWS * CAP) + (size_t)wave * ROWS * qc;
+
+    const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * rows_per_wave;   // rows_per_wave <= ROWS
+    const uint64_t j_end = j_begin + rows_per_wave < nb ? j_begin + rows_per_wave : nb;
+    const uint32_t nj = j_begin < j_end ? (uint32_t)(j_end - j_begin) : 0u;
+    const uint32_t i_begin = blockIdx.y * qc;
+    const uint32_t ni = (i_begin + qc < na ? i_begin + qc : na) - i_begin;
+    // lengths of the block's rows of A, one per lane (lanes 0..ni-1)
+    const uint32_t a_len_reg = lane < ni ? a_off[i_begin + lane + 1] - a_off[i_begin + lane] : 0u;
+
+    for (uint32_t idx = threadIdx.x; idx < ni * nw; idx += kBlock) atab_all[idx] = a_tab[(size_t)i_begin * nw + idx];
+    for (uint32_t idx = threadIdx.x; idx < ni * CAP; idx += kBlock) {
+        const uint32_t beg = a_off[i_begin + idx / CAP], len = a_off[i_begin + idx / CAP + 1] - beg;   // len <= CAP (host)
+        const uint32_t l = idx % CAP;
+        a_ids_all[idx] = l < len ? (uint32_t)a_ids[beg + l] : 0u;
+        a_val_all[idx] = (A_UNIT && l < len) ? a_data[beg + l] : 0.0f;
+    }
+    // the wave's rows of B (offsets one per lane, then all rows at once) and the output offsets of its pairs
+    const uint32_t b_off_reg = nj ? b_off[j_begin + (lane <= nj ? lane : nj)] : 0u;
+    uint32_t row_id[ROWS];
+    float row_val[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t beg = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r + 1);
+        const bool have = (uint32_t)r < nj && lane < end - beg;                  // end - beg <= CAP (host)
+        row_id[r] = have ? (uint32_t)b_ids[beg + lane] : 0u;
+        row_val[r] = (B_UNIT && have) ? b_data[beg + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        b_ids_all[r * CAP + lane] = row_id[r];
+        b_val_all[r * CAP + lane] = row_val[r];
+    }
+    for (uint32_t idx = lane; idx < nj * ni; idx += 64)
+        base_all[idx] = out_off[(uint64_t)(i_begin + idx % ni) * nb + j_begin + idx / ni];
+    __syncthreads();
+
+    for (uint32_t jr = 0; jr < nj; ++jr) {
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, (int)jr + 1) -
+                            (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, (int)jr);
+        const uint32_t* b_ids_l = b_ids_all + jr * CAP;
+        const float* b_val_l = b_val_all + jr * CAP;
+        // table of row jr of B: zero, OR the ids in, prefix the popcounts
+        for (uint32_t w = lane; w < nw; w += 64) lds_store(reinterpret_cast<u64*>(btab + w), (u64)0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane < lb) {
+            const uint32_t id = lds_load(&b_ids_l[lane]);
+            __hip_atomic_fetch_or(&btab[id >> 5].bits, 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const uint32_t c = w < nw ? (uint32_t)__builtin_popcount(lds_load(&btab[w].bits)) : 0u;
+            const uint32_t incl = wave_inclusive_scan(c);
+            if (w < nw) lds_store(&btab[w].below, run + incl - c);
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        for (uint32_t ii0 = 0; ii0 < ni; ii0 += GROUPS) {
+            // my group's row of A (groups past the last row idle: their rows have no live elements)
+            const bool valid = ii0 + grp < ni;
+            const uint32_t ii = valid ? ii0 + grp : 0u;
+            const uint32_t la = valid ? (uint32_t)__shfl((int)a_len_reg, (int)ii) : 0u;
+            const uint32_t base = lds_load(&base_all[jr * ni + ii]);
+            const RankEntry* atab = atab_all + (size_t)ii * nw;
+            const uint32_t* a_ids_l = a_ids_all + (size_t)ii * CAP;
+            const float* a_val_l = a_val_all + (size_t)ii * CAP;
+
+            // `this` and `arg` views of the pair (rows and tables in LDS)
+            const uint32_t* t_ids = SWAP ? b_ids_l : a_ids_l;
+            const float* t_val = SWAP ? b_val_l : a_val_l;
+            const uint32_t lt = SWAP ? (valid ? lb : 0u) : la;
+            const RankEntry* t_tab = SWAP ? btab : atab;
+            const uint32_t* g_ids = SWAP ? a_ids_l : b_ids_l;
+            const float* g_val = SWAP ? a_val_l : b_val_l;
+            const uint32_t lg = SWAP ? la : (valid ? lb : 0u);
+            const RankEntry* g_tab = SWAP ? atab : btab;
+
+            // Both walks, fully unrolled (rows hold at most NCH * 16 elements): all LDS reads of a stage are issued
+            // together -- ids and payloads, then the table entries, then the matches' payloads -- so a turn waits
+            // for LDS three times instead of three times per chunk.
+            uint32_t xt[NCH], rg[NCH];
+            float vt[NCH], gv[NCH];
+            bool live_t[NCH], hit_t[NCH];
+            uint32_t xg[NCH], rt[NCH];
+            float vg[NCH], tv[NCH];
+            bool live_g[NCH], hit_g[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t k = c * LP + gl;
+                live_t[c] = k < lt;
+                xt[c] = live_t[c] ? lds_load(&t_ids[k]) : 0u;
+                vt[c] = (THIS_UNIT && live_t[c]) ? lds_load(&t_val[k]) : 0.0f;
+                if constexpr (UNION) {
+                    live_g[c] = k < lg;
+                    xg[c] = live_g[c] ? lds_load(&g_ids[k]) : 0u;
+                    vg[c] = (ARG_UNIT && live_g[c]) ? lds_load(&g_val[k]) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                bool h = false;
+                rg[c] = rank_in(g_tab, xt[c], h);
+                hit_t[c] = h && live_t[c];
+                if constexpr (UNION) {
+                    bool hg = false;
+                    rt[c] = rank_in(t_tab, xg[c], hg);
+                    hit_g[c] = hg && live_g[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                // a present id's rank is its position; an absent id's read is clamped into the row and ignored
+                gv[c] = ARG_UNIT ? lds_load(&g_val[rg[c] < (uint32_t)CAP ? rg[c] : (uint32_t)CAP - 1]) : 0.0f;
+                if constexpr (DROP_BY_VALUE) tv[c] = lds_load(&t_val[rt[c] < (uint32_t)CAP ? rt[c] : (uint32_t)CAP - 1]);
+            }
+            // walk `this`: this-only elements and kept matches
+            uint32_t emitted = 0, matched = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float v = vt[c];
+                bool keep = live_t[c] && OP != SDRB_OP_AND;
+                if (hit_t[c]) {
+                    v = match_data<OP, ARG_UNIT, ARITH>(v, gv[c]);
+                    keep = match_kept<OP, THIS_UNIT, ARITH>(v);
+                }
+                uint32_t n_keep, n_hit = 0;
+                uint32_t pos = emitted + group_prefix<LP>(keep, lane, n_keep);
+                if constexpr (UNION) {
+                    pos += rg[c] - (matched + group_prefix<LP>(hit_t[c], lane, n_hit));   // arg-only elements below x
+                }
+                if (keep) {
+                    if constexpr (VISIT) {
+                        out_ids[base + pos] = (int32_t)(c * LP + gl);
+                        reinterpret_cast<uint32_t*>(out_data)[base + pos] = hit_t[c] ? rg[c] : 0xFFFFFFFFu;
+                    } else {
+                        out_ids[base + pos] = (int32_t)xt[c];
+                        if constexpr (THIS_UNIT) out_data[base + pos] = v;
+                    }
+                }
+                emitted += n_keep;
+                matched += n_hit;
+            }
+            if constexpr (UNION) {
+                // walk `arg`: its unmatched elements, converted to the result's element type
+                uint32_t singles = 0, dropped = 0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const bool single = live_g[c] && !hit_g[c];
+                    bool drop = OP == SDRB_OP_XOR && hit_g[c];   // id-only xore drops every match
+                    if constexpr (DROP_BY_VALUE) {
+                        if (hit_g[c])
+                            drop = !match_kept<OP, THIS_UNIT>(match_data<OP, ARG_UNIT>(tv[c], ARG_UNIT ? vg[c] : 0.0f));
+                    }
+                    uint32_t n_single, n_drop = 0;
+                    uint32_t pos = rt[c] + singles + group_prefix<LP>(single, lane, n_single);
+                    if constexpr (OP == SDRB_OP_XOR) pos -= dropped + group_prefix<LP>(drop, lane, n_drop);
+                    if (single) {
+                        if constexpr (VISIT) {
+                            out_ids[base + pos] = -1;
+                            reinterpret_cast<uint32_t*>(out_data)[base + pos] = c * LP + gl;
+                        } else {
+                            out_ids[base + pos] = (int32_t)xg[c];
+                            if constexpr (THIS_UNIT) out_data[base + pos] = converted_arg<ARG_UNIT, ARITH>(vg[c]);
+                        }
+                    }
+                    singles += n_single;
+                    dropped += n_drop;
+                }
+            }
+        }
+    }
+}
+
 struct Args {
     const sdrb_batch* a;
     const sdrb_batch* b;
@@ -299,6 +520,7 @@ struct Args {
     float* out_data;
     uint32_t nw, qc, cap_a, cap_b, rows_per_wave;
     bool visit;
+    bool short_rows;   // both batches hold rows of at most kShortCap elements: k_elem_rank_short
     dim3 grid;
     size_t lds;
     hipStream_t stream;
@@ -306,6 +528,20 @@ struct Args {
 
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false, bool ARITH = false>
 void launch(const Args& g) {
+    if (g.short_rows) {
+        const uint32_t longest = g.a->max_row_len > g.b->max_row_len ? g.a->max_row_len : g.b->max_row_len;
+        if (longest <= 48)
+            hipLaunchKernelGGL((k_elem_rank_short<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 3>), g.grid, dim3(kBlock), g.lds,
+                               g.stream, g.a->d_offsets, g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets,
+                               g.b->d_ids, g.b->d_data, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc,
+                               g.rows_per_wave);
+        else
+            hipLaunchKernelGGL((k_elem_rank_short<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 4>), g.grid, dim3(kBlock), g.lds,
+                               g.stream, g.a->d_offsets, g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets,
+                               g.b->d_ids, g.b->d_data, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc,
+                               g.rows_per_wave);
+        return;
+    }
     hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
                        g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets, g.b->d_ids, g.b->d_data,
                        (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc, g.cap_a, g.cap_b, g.rows_per_wave);
@@ -346,12 +582,19 @@ constexpr int32_t kMaxWidth = 32768;           // 8 KiB of table per row
 constexpr size_t kMaxTableBytes = 512u << 20;  // tables of A in global memory
 constexpr size_t kLdsWanted = 64 * 1024;       // rows of A per block are halved until a block fits this
 constexpr size_t kLdsLimit = 64 * 1024;        // what a block may use at most
+constexpr size_t kLdsShortWanted = 40 * 1024;  // short-row kernel: four blocks per compute unit
 
 struct Shape {
     uint32_t nw, qc, cap_a, cap_b;
     size_t lds;
     bool ok;
+    bool short_rows;
 };
+
+size_t lds_bytes_short(uint32_t nw, uint32_t qc) {
+    return ((size_t)kWaves * nw + (size_t)qc * nw) * sizeof(RankEntry) + (size_t)qc * kShortCap * 8 +
+           (size_t)kWaves * kShortRows * kShortCap * 8 + (size_t)kWaves * kShortRows * qc * 4;
+}
 
 size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b) {
     return ((size_t)kWaves * nw + (size_t)qc * nw) * sizeof(RankEntry) + ((size_t)qc * cap_a + (size_t)kWaves * cap_b) * 8;
@@ -367,6 +610,18 @@ Shape shape_for(const sdrb_batch* a, const sdrb_batch* b) {
     if (s.cap_a == 0) s.cap_a = 64;
     if (s.cap_b == 0) s.cap_b = 64;
     s.qc = kQueryChunk;
+    // short rows on both sides and enough rows of A to fill the four lane groups: the short-row kernel
+    s.short_rows = a->max_row_len <= (uint32_t)kShortCap && b->max_row_len <= (uint32_t)kShortCap && a->n_rows >= 4;
+    if (s.short_rows) {
+        while (s.qc > 4 && lds_bytes_short(s.nw, s.qc) > kLdsShortWanted) s.qc >>= 1;
+        s.lds = lds_bytes_short(s.nw, s.qc);
+        if (s.lds <= kLdsLimit) {
+            s.ok = true;
+            return s;
+        }
+        s.short_rows = false;
+        s.qc = kQueryChunk;
+    }
     while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b) > kLdsWanted) s.qc >>= 1;
     s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b);
     s.ok = s.lds <= kLdsLimit;
@@ -403,6 +658,7 @@ int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
     g.out_ids = out_ids;
     g.out_data = out_data;
     g.visit = visit;
+    g.short_rows = shape.short_rows;
     g.nw = nw;
     g.qc = shape.qc;
     g.cap_a = shape.cap_a;
@@ -412,7 +668,7 @@ int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
     // enough waves to fill the chip, few enough that each amortises its tables
     const uint64_t nb = b->n_rows;
     const uint64_t ychunks = (a->n_rows + g.qc - 1) / g.qc;
-    uint32_t rpw = 16;
+    uint32_t rpw = shape.short_rows ? (uint32_t)kShortRows : 16u;
     while (rpw > 1 && (nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves) * ychunks < 4096) rpw >>= 1;
     g.rows_per_wave = rpw;
     g.grid = dim3((uint32_t)((nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves)), (uint32_t)ychunks);
