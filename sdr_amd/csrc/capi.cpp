@@ -186,10 +186,13 @@ struct IdView {
         v.owns_storage = false;
     }
     ~IdView() {
+        // only what was built through THIS view is handed back (two views of one batch may be alive at once)
         sdrb_batch* m = const_cast<sdrb_batch*>(src);
-        m->d_bitplanes = v.d_bitplanes;
-        m->d_dense8 = v.d_dense8;
-        m->dense_chunks = v.dense_chunks;
+        if (v.d_bitplanes != src->d_bitplanes && v.d_bitplanes) m->d_bitplanes = v.d_bitplanes;
+        if (v.d_dense8 != src->d_dense8 && v.d_dense8) {
+            m->d_dense8 = v.d_dense8;
+            m->dense_chunks = v.dense_chunks;
+        }
     }
 };
 

@@ -106,6 +106,18 @@ def test_rowwise_and_64_bit_ids():
         assert_same(getattr(lt, name)(la).to_host(), oracle.port().visit(which, t, a))
 
 
+def test_batch_against_itself_with_long_rows():
+    # rows longer than a wave: the count runs through the dense-bitset kernel, whose derived bit planes are
+    # built through payload-free views of the batch -- twice the same batch here, and again on a second call
+    rng = np.random.default_rng(10)
+    t = Batch(*util.ragged_rows(rng, 40, 512, 200, True))
+    d = dev(t, 512)
+    for _ in range(2):
+        for which, name in VISITORS.items():
+            assert_same(getattr(d, name)(d).to_host(), oracle.port().visit(which, t, t))
+    assert np.array_equal(d.ands(d).cpu().numpy().view(np.uint32), oracle.port().size_op(oracle.AND, t, t))
+
+
 def test_empty_rows_and_batches():
     e = SDRBatch.from_rows([[], [], []], width=64)
     some = SDRBatch.from_rows([[1, 5], [], [0, 1, 63]], width=64)
