@@ -173,6 +173,16 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
                  uint32_t* out, uint64_t ld_out, void* stream);
 
 /*
+ * Equality for every pair: out[i*ld_out + j] = (A_i == B_j) ? 1 : 0  -- SDR::operator== (SDR.hpp:470-483): the same
+ * number of elements, the same ids position by position and, where BOTH batches carry payloads, payloads that
+ * compare equal as floats (UnitData.hpp:122-124, ArithData.hpp:90-92; a payload always equals EmptyData,
+ * UnitData.hpp:130-132).  SDRB_FLAG_ROWWISE: out[j] = (A_j == B_j).  Ids of 32 or 64 bits; UnitData and ArithData
+ * batches do not combine, and an EmptyData A takes an EmptyData B only (the reference compiles no other: EmptyData
+ * has no != for a payload, EmptyData.hpp:82-83).
+ */
+int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream);
+
+/*
  * Sparse dot products for every pair: out[i*ld_out + j] (float, device memory, ld_out >= B rows)
  *   = A_i.inner(B_j)  (SDR.hpp:1682-1692): over the id matches in ascending id order,
  *     acc += a_value * b_value, a rounded product followed by a rounded sum (ArithData.hpp:37-43,

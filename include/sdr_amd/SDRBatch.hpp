@@ -388,6 +388,13 @@ class SDRBatch {
     SDRBatch& xori(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_XOR, arg, stream); }
     SDRBatch& rmi(const SDRBatch& arg, void* stream = nullptr) { return inplace(SDRB_OP_RM, arg, stream); }
 
+    // out(i, j) = ((*this)[i] == db[j]) as 1 / 0 -- SDR::operator== (SDR.hpp:470-483); SDRB_FLAG_ROWWISE: out(0, j) for row j of both
+    Counts equals(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const {
+        Counts c(db.device_, (flags & SDRB_FLAG_ROWWISE) ? 1 : n_rows_, db.n_rows_);
+        check(sdrb_equal(h_, db.h_, flags, c.device_ptr(), db.n_rows_, stream));
+        return c;
+    }
+
     // Batched visitors (the reference's extension API, README.md:133-155): the calls that
     // (*this)[i].andv(db[j], visitor) (SDR.hpp:186-194) and (*this)[i].orv(db[j], this_v, arg_v, both_v)
     // (SDR.hpp:268-269) make, as arrays of element positions -- the raw material for custom operations.

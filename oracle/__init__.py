@@ -195,6 +195,14 @@ class _Impl:
            a.data.ctypes.data_as(_vp) if a.data is not None else None, a.n, out.ctypes.data_as(_vp))
         return out
 
+    def equal(self, t: Batch, a: Batch) -> np.ndarray:
+        """uint32 [t.n, a.n]: 1 where this_i == arg_j (SDR::operator==, SDR.hpp:470-483)."""
+        fn = getattr(self.lib, self.prefix + "batch_equal")
+        fn.restype, fn.argtypes = None, _BATCH_ARGS + [_vp]
+        out = np.zeros((t.n, a.n), dtype=np.uint32)
+        fn(*t.args(), *a.args(), out.ctypes.data_as(_vp))
+        return out
+
     def visit(self, which: int, t: Batch, a: Batch):
         """The callbacks of andv (``which`` 0) / orv (``which`` 1) of every pair, in call order:
         (offsets uint64 [t.n*a.n+1], this_pos uint32, arg_pos uint32); 0xFFFFFFFF marks the absent side of

@@ -340,6 +340,26 @@ void rsdr_batch_point(const uint64_t* off, const int32_t* ids, const float* data
     }
 }
 
+/* this_i == arg_j with the reference's operator== (SDR.hpp:470-483).  The reference compiles it for an EmptyData
+ * `this` only against EmptyData (EmptyData has no != for payloads), so those are the pairings served. */
+void rsdr_batch_equal(const uint64_t* t_off, const int32_t* t_ids, const float* t_data, int t_kind, uint64_t t_n,
+                      const uint64_t* a_off, const int32_t* a_ids, const float* a_data, int a_kind, uint64_t a_n,
+                      uint32_t* out) {
+#define CALL(A, B)                                          \
+    do {                                                    \
+        auto t = build<A>(t_off, t_ids, t_data, t_n);       \
+        auto a = build<B>(a_off, a_ids, a_data, a_n);       \
+        for (size_t i = 0; i < t.size(); ++i)               \
+            for (size_t j = 0; j < a.size(); ++j) out[i * a.size() + j] = (t[i] == a[j]) ? 1u : 0u; \
+    } while (0)
+    if (t_kind == K_EMPTY && a_kind == K_EMPTY) CALL(EmptySDR, EmptySDR);
+    else if (t_kind == K_UNIT && a_kind == K_UNIT) CALL(UnitSDR, UnitSDR);
+    else if (t_kind == K_UNIT && a_kind == K_EMPTY) CALL(UnitSDR, EmptySDR);
+    else if (t_kind == K_ARITH && a_kind == K_ARITH) CALL(ArithSDR, ArithSDR);
+    else if (t_kind == K_ARITH && a_kind == K_EMPTY) CALL(ArithSDR, EmptySDR);
+#undef CALL
+}
+
 /* What the reference's visitors are called with: andv (which = 0, SDR.hpp:186-194) and orv (which = 1,
  * SDR.hpp:268-269) on SDR<SDRElem<int, EmptyData>> rows in std::vector containers, every callback recorded
  * as (this position, arg position); 0xFFFFFFFF marks the absent side of an orv single. */

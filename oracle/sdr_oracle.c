@@ -431,6 +431,28 @@ void osdr_batch_inner(const uint64_t* t_off, const int32_t* t_ids, const float* 
         }
 }
 
+/* ---- operator== (SDR.hpp:470-483) --------------------------------------------------------- */
+/* payload != : float compare when both sides carry a payload of the same kind (UnitData.hpp:122-128,
+ * ArithData.hpp:90-96), never unequal against EmptyData (UnitData.hpp:130-136, EmptyData.hpp:82-83). */
+void osdr_batch_equal(const uint64_t* t_off, const int32_t* t_ids, const float* t_data, int t_kind, uint64_t t_n,
+                      const uint64_t* a_off, const int32_t* a_ids, const float* a_data, int a_kind, uint64_t a_n,
+                      uint32_t* out) {
+    const int payloads = t_kind != OSDR_EMPTY && a_kind != OSDR_EMPTY;
+    for (uint64_t i = 0; i < t_n; ++i)
+        for (uint64_t j = 0; j < a_n; ++j) {
+            uint64_t tp = t_off[i], te = t_off[i + 1], ap = a_off[j], ae = a_off[j + 1];
+            uint32_t same;
+            for (;;) {
+                if (tp == te) { same = ap == ae; break; }                  /* :477 */
+                if (ap == ae) { same = 0; break; }                         /* :478 */
+                if (t_ids[tp] != a_ids[ap] || (payloads && t_data[tp] != a_data[ap])) { same = 0; break; }   /* :481 */
+                ++tp;
+                ++ap;
+            }
+            out[i * a_n + j] = same;
+        }
+}
+
 /* ---- the visit sequences themselves (what andv / orv hand to their callbacks) ------------- */
 typedef struct {
     uint32_t* this_pos;

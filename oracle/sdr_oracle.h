@@ -108,6 +108,11 @@ uint64_t osdr_batch_elem_op(int op,
                             int a_kind, uint64_t a_n,
                             uint64_t* out_off, int32_t* out_ids, float* out_data);
 
+/* out[i*a_n + j] = (this_i == arg_j), SDR::operator== (SDR.hpp:470-483): 1 or 0. */
+void osdr_batch_equal(const uint64_t* t_off, const int32_t* t_ids, const float* t_data, int t_kind, uint64_t t_n,
+                      const uint64_t* a_off, const int32_t* a_ids, const float* a_data, int a_kind, uint64_t a_n,
+                      uint32_t* out);
+
 /* The callbacks of andv (which = 0, SDR.hpp:958-997) or orv (which = 1, SDR.hpp:1099-1166) of every pair, in
  * call order, as (this position, arg position) records; the absent side of an orv single is 0xFFFFFFFF.
  * out_off has t_n*a_n+1 entries; this_pos / arg_pos may be NULL (count only).  Returns the total. */

@@ -433,6 +433,22 @@ class SDRBatch:
         """Every row becomes ``row.rmi(other[j])`` (SDR.hpp:1436-1513)."""
         return self._inplace("rme", other, stream)
 
+    def equals(self, other: "SDRBatch", *, rowwise=False, stream=None):
+        """``out[i, j] = (self[i] == other[j])`` as 0/1 (int32), the reference's ``operator==`` (SDR.hpp:470-483):
+        same ids in the same positions and, where both batches carry payloads, equal payloads.  ``rowwise``:
+        ``out[j] = (self[j] == other[j])``."""
+        torch = _torch()
+        dev = f"cuda:{other.device}"
+        if rowwise:
+            if self.n_rows != other.n_rows:
+                raise ValueError("row-wise evaluation needs batches of equal length")
+            out = torch.empty(max(other.n_rows, 1), dtype=torch.int32, device=dev)
+        else:
+            out = torch.empty((max(self.n_rows, 1), max(other.n_rows, 1)), dtype=torch.int32, device=dev)
+        check(self._lib.sdrb_equal(self._h, other._h, FLAG_ROWWISE if rowwise else 0, out.data_ptr(),
+                                   other.n_rows, _stream_handle(other.device, stream)))
+        return out[: other.n_rows] if rowwise else out[: self.n_rows, : other.n_rows]
+
     # -- batched visitors ------------------------------------------------------------------------
     def _visit(self, which: int, other: "SDRBatch", swap, stream, algo, rowwise) -> VisitResult:
         torch = _torch()

@@ -714,6 +714,33 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
 }
 
+int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream) {
+    int rc = check_pair(a, b, SDRB_OP_AND);
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
+    if (rc != SDRB_OK) return rc;
+    if (!has_payload(a) && has_payload(b)) {
+        // the reference does not compile this comparison either (EmptyData has no != for a payload, EmptyData.hpp:82-83)
+        set_error("EmptyData rows compare with EmptyData rows only; put the batch with payloads first");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+    if (rowwise && a->n_rows != b->n_rows) {
+        set_error("row-wise evaluation needs batches of equal length");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || (!rowwise && ld_out < b->n_rows)) {
+        set_error("sdrb_equal: out is null or ld_out < rows of b");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_equal(a, b, out, ld_out, rowwise, static_cast<hipStream_t>(stream));
+}
+
 static int sdrb_batch_transpose_impl(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
     if (!src || !dst || src == dst || !src->d_offsets) {
         set_error("sdrb_batch_transpose: null, identical or empty handles");

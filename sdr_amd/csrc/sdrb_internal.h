@@ -92,6 +92,10 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
 int launch_size_merge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                       uint32_t* out, uint64_t ld_out, bool rowwise, hipStream_t stream);
 
+// SDR::operator== for every pair (or row-wise): out = 1 / 0
+int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out, bool rowwise,
+                 hipStream_t stream);
+
 // elem_ops.hip --------------------------------------------------------------------
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream);
 // out_ids: int32 ids, or int64 ids when the batches hold 64-bit ids

@@ -60,6 +60,30 @@ __global__ __launch_bounds__(kBlock) void k_size_merge(
     }
 }
 
+// SDR::operator== (SDR.hpp:470-483) for every pair: equal lengths, equal ids position by position, and --
+// only when both sides carry payloads -- equal payloads (float ==, UnitData.hpp:122-124, ArithData.hpp:90-92;
+// a payload always equals EmptyData, UnitData.hpp:130-132).  out = 1 / 0.
+template <typename ID, bool PAYLOADS>
+__global__ __launch_bounds__(kBlock) void k_equal(const uint32_t* __restrict__ a_off, const ID* __restrict__ a_ids,
+                                                  const float* __restrict__ a_data, uint64_t na,
+                                                  const uint32_t* __restrict__ b_off, const ID* __restrict__ b_ids,
+                                                  const float* __restrict__ b_data, uint64_t nb,
+                                                  uint32_t* __restrict__ out, uint64_t ld_out, uint32_t rowwise) {
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= nb) return;
+    const uint32_t b_beg = b_off[j];
+    const uint32_t lb = b_off[j + 1] - b_beg;
+    for (uint64_t i = rowwise ? j : blockIdx.y; i < na; i += rowwise ? na : gridDim.y) {
+        const uint32_t a_beg = a_off[i];
+        bool same = a_off[i + 1] - a_beg == lb;
+        for (uint32_t k = 0; same && k < lb; ++k) {
+            same = a_ids[a_beg + k] == b_ids[b_beg + k];
+            if constexpr (PAYLOADS) same = same && a_data[a_beg + k] == b_data[b_beg + k];
+        }
+        out[(rowwise ? 0 : i * ld_out) + j] = same ? 1u : 0u;
+    }
+}
+
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT>
 void launch(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out, bool rowwise,
             hipStream_t stream) {
@@ -94,6 +118,28 @@ void launch_swap(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_t* 
 }
 
 }  // namespace
+
+int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64_t ld_out, bool rowwise,
+                 hipStream_t stream) {
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    const dim3 grid((uint32_t)((b->n_rows + kBlock - 1) / kBlock),
+                    rowwise ? 1u : (uint32_t)(a->n_rows < 65535 ? a->n_rows : 65535));
+    const bool payloads = has_payload(a) && has_payload(b);
+#define SDRB_EQ(ID, P)                                                                                                    \
+    hipLaunchKernelGGL((k_equal<ID, P>), grid, dim3(kBlock), 0, stream, a->d_offsets, reinterpret_cast<const ID*>(a->d_ids), \
+                       a->d_data, a->n_rows, b->d_offsets, reinterpret_cast<const ID*>(b->d_ids), b->d_data, b->n_rows, out, \
+                       ld_out, rowwise ? 1u : 0u)
+    if (a->id_bits == 64) {
+        if (payloads) SDRB_EQ(long long, true);
+        else SDRB_EQ(long long, false);
+    } else {
+        if (payloads) SDRB_EQ(int32_t, true);
+        else SDRB_EQ(int32_t, false);
+    }
+#undef SDRB_EQ
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
 
 int launch_size_merge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
                       uint64_t ld_out, bool rowwise, hipStream_t stream) {

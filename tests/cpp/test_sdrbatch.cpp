@@ -302,6 +302,24 @@ int run_visitors(std::mt19937& rng, const char* name) {
                       });
             REQUIRE(ok && k == ov.offsets[p + 1]);
         }
+    // operator== for every pair (a few rows are made equal on purpose)
+    for (size_t r : {size_t(1), size_t(2)}) {
+        SDR<E> same;
+        for (auto it = qs[r].cbegin(); it != qs[r].cend(); ++it) same.push_back(E(it->id()));
+        ds[2 * r + 1] = same;
+    }
+    auto d2 = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 300);
+    auto eq = q.equals(d2).to_host();
+    long n_equal = 0;
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            REQUIRE((eq[i * ds.size() + j] != 0) == (qs[i] == ds[j]));
+            n_equal += eq[i * ds.size() + j];
+        }
+    REQUIRE(n_equal >= 2);
+    auto self = q.equals(q).to_host();
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < qs.size(); ++j) REQUIRE((self[i * qs.size() + j] != 0) == (qs[i] == qs[j]));
     std::printf("ok %-28s %ld checks so far\n", name, g_checks);
     return 0;
 }

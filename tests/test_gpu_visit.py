@@ -118,6 +118,29 @@ def test_batch_against_itself_with_long_rows():
     assert np.array_equal(d.ands(d).cpu().numpy().view(np.uint32), oracle.port().size_op(oracle.AND, t, t))
 
 
+def test_operator_equal_vs_golden_and_oracle(golden):
+    # SDR::operator== for every pair and row-wise, every pairing the reference compiles, 32- and 64-bit ids
+    from test_oracle_golden import equal_cases
+    g = golden("equal.npz")
+    for tag, (t, a) in equal_cases(g).items():
+        kt = "arith" if t.kind == oracle.ARITH else None
+        ka = "arith" if a.kind == oracle.ARITH else None
+        for width in (6, 0):
+            dt = SDRBatch.from_csr(t.off, t.ids, t.data, width=width, kind=kt)
+            da = SDRBatch.from_csr(a.off, a.ids, a.data, width=width, kind=ka)
+            got = dt.equals(da).cpu().numpy()
+            assert np.array_equal(got, g[tag]), tag
+            assert np.array_equal(dt.equals(da, rowwise=True).cpu().numpy(), np.diagonal(g[tag]))
+    rng = np.random.default_rng(12)
+    t = Batch(*util.ragged_rows(rng, 60, 50, 6, True))
+    a = Batch(*util.ragged_rows(rng, 90, 50, 6, True))
+    assert np.array_equal(dev(t, 50).equals(dev(a, 50)).cpu().numpy(), oracle.port().equal(t, a))
+    wide = lambda b: SDRBatch.from_csr(b.off, b.ids.astype(np.int64) * 0x100000003, b.data)   # noqa: E731
+    assert np.array_equal(wide(t).equals(wide(a)).cpu().numpy(), oracle.port().equal(t, a))
+    with pytest.raises(sdr_amd.SdrbError):      # the reference does not compile EmptyData == payload either
+        dev(Batch(t.off, t.ids), 50).equals(dev(a, 50))
+
+
 def test_empty_rows_and_batches():
     e = SDRBatch.from_rows([[], [], []], width=64)
     some = SDRBatch.from_rows([[1, 5], [], [0, 1, 63]], width=64)

@@ -170,6 +170,21 @@ def test_arith_set_algebra_vs_golden(golden):
             assert np.array_equal(np.diff(off).reshape(t.n, a.n), g[f"{tag}_size{op}"])   # ands == ande.size() ...
 
 
+def equal_cases(g):
+    off, ids, data = util.fuzz_universe(64, int(g["seed"]))
+    e, u, v = Batch(off, ids), Batch(off, ids, data), Batch(off, ids, g["changed"])
+    x, y = Batch(off, ids, g["arith"], arith=True), Batch(off, ids, np.abs(g["arith"]), arith=True)
+    return {"EE": (e, e), "UU": (u, v), "UE": (u, e), "AA": (x, y), "AE": (x, e)}
+
+
+def test_operator_equal_vs_golden(golden):
+    """SDR::operator== (SDR.hpp:470-483): ids position by position, payloads only where both sides have them."""
+    g = golden("equal.npz")
+    for tag, (t, a) in equal_cases(g).items():
+        assert np.array_equal(oracle.port().equal(t, a), g[tag]), tag
+    assert g["EE"].sum() == 64 and g["UE"].sum() == 64 and 0 < g["UU"].sum() < 64
+
+
 def test_visitor_call_sequences_vs_golden(golden):
     """andv / orv (SDR.hpp:958-997, 1099-1166): the restatement calls its visitors with the positions the
     reference's own visitors received."""

@@ -21,6 +21,7 @@ Fixtures
   mini_16k_328.npz  4 queries x 512 rows, width 16384 / 328 active, UnitData x UnitData.
   inplace.npz       andi/ori/xori/rmi on a 5-id universe incl. the aliased a.op(a) cases.
   arith.npz         and / or / rm on ArithData<float> rows (sizes, element-op lengths and digests).
+  equal.npz         operator== for every pair of the 6-id universe, with and without payloads.
   visit.npz         the calls of the reference's andv / orv visitors (positions in this and arg) on the
                     6-id fuzz universe (64x64 pairs, complete) and on ragged rows (lengths and digests).
 """
@@ -292,6 +293,28 @@ def gen_arith():
     np.savez_compressed(os.path.join(OUT, "arith.npz"), **out)
 
 
+def gen_equal():
+    """SDR::operator== (SDR.hpp:470-483) on the 6-id fuzz universe: ids alone, payloads on both sides (a copy
+    with some payloads changed, signed zeros and all), payloads against none, and ArithData rows."""
+    out = {}
+    off, ids, data = util.fuzz_universe(64, FUZZ_SEED)
+    changed = data.copy()
+    changed[::5] = np.float32(0.75)
+    changed[3::11] = data[3::11]                       # keep some rows fully equal
+    e = oracle.Batch(off, ids)
+    u = oracle.Batch(off, ids, data)
+    v = oracle.Batch(off, ids, changed)
+    rng = np.random.default_rng(FUZZ_SEED + 41)
+    arith = (rng.integers(-2, 3, ids.size)).astype(np.float32)
+    arith[arith == 0] = np.float32(-0.0)               # -0 == +0 in the comparison
+    x = oracle.Batch(off, ids, arith, arith=True)
+    y = oracle.Batch(off, ids, np.abs(arith), arith=True)
+    out.update(changed=changed, arith=arith)
+    for tag, (t, a) in {"EE": (e, e), "UU": (u, v), "UE": (u, e), "AA": (x, y), "AE": (x, e)}.items():
+        out[tag] = both("equal", t, a).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "equal.npz"), seed=FUZZ_SEED, **out)
+
+
 def gen_visit():
     """What andv / orv call their visitors with (SDR.hpp:186-194,268-269), taken from the reference's own
     visitors on std::vector rows; the restatement must produce the same call sequences."""
@@ -332,6 +355,10 @@ def main():
     if sys.argv[1:] == ["arith"]:
         gen_arith()
         return
+    if sys.argv[1:] == ["equal"]:
+        gen_equal()
+        return
+    gen_equal()
     gen_arith()
     gen_visit()
     gen_inner()
