@@ -511,6 +511,230 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank_short(
     }
 }
 
+// ---------------------------------------------------------------- short rows, narrow widths: coalesced runs
+// Scattered 64-byte pieces are what bounds the short-row kernel (without its stores it runs almost three times
+// as fast), so here the four lane groups of a turn work on four CONSECUTIVE rows of B against the same row of A:
+// their results are neighbours in the output, are staged back to back in LDS and leave the wave as one
+// coalesced run.  For that the tables of all of the wave's rows of B stay resident (kRunRows rows, so this
+// kernel is for widths whose tables are small), and a pair's place in the run comes from the output offsets.
+constexpr int kRunRows = 4;          // rows of B per wave = lane groups per turn
+constexpr int kRunStage = 4 * 2 * kShortCap;   // elements a run can hold (four unions of two full rows)
+
+template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT, bool ARITH, int NCH>
+__global__ __launch_bounds__(kBlock) void k_elem_rank_runs(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_data,
+    uint32_t na, const RankEntry* __restrict__ a_tab, const uint32_t* __restrict__ b_off,
+    const int32_t* __restrict__ b_ids, const float* __restrict__ b_data, uint32_t nb,
+    const uint32_t* __restrict__ out_off, int32_t* __restrict__ out_ids, float* __restrict__ out_data,
+    uint32_t nw, uint32_t qc) {
+    constexpr bool THIS_UNIT = SWAP ? B_UNIT : A_UNIT;
+    constexpr bool ARG_UNIT = SWAP ? A_UNIT : B_UNIT;
+    constexpr bool UNION = OP == SDRB_OP_OR || OP == SDRB_OP_XOR;
+    constexpr bool DROP_BY_VALUE = OP == SDRB_OP_XOR && THIS_UNIT;
+    constexpr bool SECOND = THIS_UNIT || VISIT;   // the run has a second array (payloads / arg positions)
+    constexpr int LP = 16, CAP = kShortCap, ROWS = kRunRows;
+    // LDS: tables of the block's rows of A | rows of A: ids, payloads | per wave: tables of its rows of B,
+    //      those rows: ids, payloads | output offsets of its pairs ((ROWS + 1) per row of A) | the run: two arrays
+    extern __shared__ RankEntry smem[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t grp = lane / LP, gl = lane % LP;
+    RankEntry* atab_all = smem;
+    uint32_t* a_ids_all = reinterpret_cast<uint32_t*>(atab_all + (size_t)qc * nw);
+    float* a_val_all = reinterpret_cast<float*>(a_ids_all + (size_t)qc * CAP);
+    const size_t per_wave_words = (size_t)ROWS * nw * 2 + (size_t)ROWS * CAP * 2 + (size_t)(ROWS + 1) * qc + 2 * kRunStage;
+    uint32_t* mine = reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * CAP) + (size_t)wave * per_wave_words;
+    RankEntry* btab_all = reinterpret_cast<RankEntry*>(mine);
+    uint32_t* b_ids_all = mine + (size_t)ROWS * nw * 2;
+    float* b_val_all = reinterpret_cast<float*>(b_ids_all + ROWS * CAP);
+    uint32_t* base_all = b_ids_all + 2 * ROWS * CAP;        // [row of A][ROWS + 1]
+    uint32_t* run_a = base_all + (ROWS + 1) * qc;           // ids / this positions
+    uint32_t* run_b = run_a + kRunStage;                    // payload bits / arg positions
+
+    const uint64_t j_begin = ((uint64_t)blockIdx.x * kWaves + wave) * ROWS;
+    const uint64_t j_end = j_begin + ROWS < nb ? j_begin + ROWS : nb;
+    const uint32_t nj = j_begin < j_end ? (uint32_t)(j_end - j_begin) : 0u;
+    const uint32_t i_begin = blockIdx.y * qc;
+    const uint32_t ni = (i_begin + qc < na ? i_begin + qc : na) - i_begin;
+
+    for (uint32_t idx = threadIdx.x; idx < ni * nw; idx += kBlock) atab_all[idx] = a_tab[(size_t)i_begin * nw + idx];
+    for (uint32_t idx = threadIdx.x; idx < ni * CAP; idx += kBlock) {
+        const uint32_t beg = a_off[i_begin + idx / CAP], len = a_off[i_begin + idx / CAP + 1] - beg;   // len <= CAP (host)
+        const uint32_t l = idx % CAP;
+        a_ids_all[idx] = l < len ? (uint32_t)a_ids[beg + l] : 0u;
+        a_val_all[idx] = (A_UNIT && l < len) ? a_data[beg + l] : 0.0f;
+    }
+    // lengths of the block's rows of A, one per lane; the wave's rows of B, their tables, its output offsets
+    const uint32_t a_len_reg = lane < ni ? a_off[i_begin + lane + 1] - a_off[i_begin + lane] : 0u;
+    const uint32_t b_off_reg = nj ? b_off[j_begin + (lane <= nj ? lane : nj)] : 0u;
+    uint32_t row_id[ROWS];
+    float row_val[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t beg = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r + 1);
+        const bool have = (uint32_t)r < nj && lane < end - beg;                  // end - beg <= CAP (host)
+        row_id[r] = have ? (uint32_t)b_ids[beg + lane] : 0u;
+        row_val[r] = (B_UNIT && have) ? b_data[beg + lane] : 0.0f;
+    }
+    for (uint32_t idx = lane; idx < ni * (ROWS + 1); idx += 64) {
+        const uint32_t ii = idx / (ROWS + 1), r = idx % (ROWS + 1);
+        // offsets of the pairs (i, j_begin + r); entry nj closes the last pair's result
+        base_all[idx] = r <= nj ? out_off[(uint64_t)(i_begin + ii) * nb + j_begin + r] : 0u;
+    }
+    for (uint32_t w = lane; w < ROWS * nw; w += 64) lds_store(reinterpret_cast<u64*>(btab_all + w), (u64)0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r + 1) -
+                             (uint32_t)__builtin_amdgcn_readlane((int)b_off_reg, r);
+        b_ids_all[r * CAP + lane] = row_id[r];
+        b_val_all[r * CAP + lane] = row_val[r];
+        if ((uint32_t)r < nj && lane < len)
+            __hip_atomic_fetch_or(&btab_all[r * nw + (row_id[r] >> 5)].bits, 1u << (row_id[r] & 31), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t r = 0; r < (uint32_t)ROWS; ++r) {
+        uint32_t run = 0;
+        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const uint32_t c = w < nw ? (uint32_t)__builtin_popcount(lds_load(&btab_all[r * nw + w].bits)) : 0u;
+            const uint32_t incl = wave_inclusive_scan(c);
+            if (w < nw) lds_store(&btab_all[r * nw + w].below, run + incl - c);
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    __syncthreads();
+    if (nj == 0) return;
+
+    // my group's row of B (groups past the last row idle: their rows have no live elements)
+    const bool valid = grp < nj;
+    const uint32_t jr = valid ? grp : 0u;
+    const uint32_t lb = valid ? (uint32_t)__shfl((int)b_off_reg, (int)jr + 1) - (uint32_t)__shfl((int)b_off_reg, (int)jr) : 0u;
+    const RankEntry* btab = btab_all + (size_t)jr * nw;
+    const uint32_t* b_ids_l = b_ids_all + jr * CAP;
+    const float* b_val_l = b_val_all + jr * CAP;
+
+    for (uint32_t ii = 0; ii < ni; ++ii) {
+        const uint32_t la = valid ? (uint32_t)__builtin_amdgcn_readlane((int)a_len_reg, (int)ii) : 0u;
+        const uint32_t run_base = lds_load(&base_all[ii * (ROWS + 1)]);
+        const uint32_t run_len = lds_load(&base_all[ii * (ROWS + 1) + nj]) - run_base;
+        const uint32_t rel = lds_load(&base_all[ii * (ROWS + 1) + jr]) - run_base;   // my pair's place in the run
+        const RankEntry* atab = atab_all + (size_t)ii * nw;
+        const uint32_t* a_ids_l = a_ids_all + (size_t)ii * CAP;
+        const float* a_val_l = a_val_all + (size_t)ii * CAP;
+
+        // `this` and `arg` views of the pair (rows and tables in LDS)
+        const uint32_t* t_ids = SWAP ? b_ids_l : a_ids_l;
+        const float* t_val = SWAP ? b_val_l : a_val_l;
+        const uint32_t lt = SWAP ? lb : la;
+        const RankEntry* t_tab = SWAP ? btab : atab;
+        const uint32_t* g_ids = SWAP ? a_ids_l : b_ids_l;
+        const float* g_val = SWAP ? a_val_l : b_val_l;
+        const uint32_t lg = SWAP ? la : lb;
+        const RankEntry* g_tab = SWAP ? atab : btab;
+
+        // Both walks, fully unrolled (rows hold at most NCH * 16 elements): all LDS reads of a stage are issued
+        // together -- ids and payloads, then the table entries, then the matches' payloads.
+        uint32_t xt[NCH], rg[NCH];
+        float vt[NCH], gv[NCH];
+        bool live_t[NCH], hit_t[NCH];
+        uint32_t xg[NCH], rt[NCH];
+        float vg[NCH], tv[NCH];
+        bool live_g[NCH], hit_g[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t k = c * LP + gl;
+            live_t[c] = k < lt;
+            xt[c] = live_t[c] ? lds_load(&t_ids[k]) : 0u;
+            vt[c] = (THIS_UNIT && live_t[c]) ? lds_load(&t_val[k]) : 0.0f;
+            if constexpr (UNION) {
+                live_g[c] = k < lg;
+                xg[c] = live_g[c] ? lds_load(&g_ids[k]) : 0u;
+                vg[c] = (ARG_UNIT && live_g[c]) ? lds_load(&g_val[k]) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            bool h = false;
+            rg[c] = rank_in(g_tab, xt[c], h);
+            hit_t[c] = h && live_t[c];
+            if constexpr (UNION) {
+                bool hg = false;
+                rt[c] = rank_in(t_tab, xg[c], hg);
+                hit_g[c] = hg && live_g[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // a present id's rank is its position; an absent id's read is clamped into the row and ignored
+            gv[c] = ARG_UNIT ? lds_load(&g_val[rg[c] < (uint32_t)CAP ? rg[c] : (uint32_t)CAP - 1]) : 0.0f;
+            if constexpr (DROP_BY_VALUE) tv[c] = lds_load(&t_val[rt[c] < (uint32_t)CAP ? rt[c] : (uint32_t)CAP - 1]);
+        }
+        // walk `this`: this-only elements and kept matches
+        uint32_t emitted = 0, matched = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float v = vt[c];
+            bool keep = live_t[c] && OP != SDRB_OP_AND;
+            if (hit_t[c]) {
+                v = match_data<OP, ARG_UNIT, ARITH>(v, gv[c]);
+                keep = match_kept<OP, THIS_UNIT, ARITH>(v);
+            }
+            uint32_t n_keep, n_hit = 0;
+            uint32_t pos = rel + emitted + group_prefix<LP>(keep, lane, n_keep);
+            if constexpr (UNION) {
+                pos += rg[c] - (matched + group_prefix<LP>(hit_t[c], lane, n_hit));   // arg-only elements below x
+            }
+            if (keep) {
+                if constexpr (VISIT) {
+                    lds_store(&run_a[pos], (uint32_t)(c * LP + gl));
+                    lds_store(&run_b[pos], hit_t[c] ? rg[c] : 0xFFFFFFFFu);
+                } else {
+                    lds_store(&run_a[pos], xt[c]);
+                    if constexpr (THIS_UNIT) lds_store(&run_b[pos], __float_as_uint(v));
+                }
+            }
+            emitted += n_keep;
+            matched += n_hit;
+        }
+        if constexpr (UNION) {
+            // walk `arg`: its unmatched elements, converted to the result's element type
+            uint32_t singles = 0, dropped = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bool single = live_g[c] && !hit_g[c];
+                bool drop = OP == SDRB_OP_XOR && hit_g[c];   // id-only xore drops every match
+                if constexpr (DROP_BY_VALUE) {
+                    if (hit_g[c])
+                        drop = !match_kept<OP, THIS_UNIT>(match_data<OP, ARG_UNIT>(tv[c], ARG_UNIT ? vg[c] : 0.0f));
+                }
+                uint32_t n_single, n_drop = 0;
+                uint32_t pos = rel + rt[c] + singles + group_prefix<LP>(single, lane, n_single);
+                if constexpr (OP == SDRB_OP_XOR) pos -= dropped + group_prefix<LP>(drop, lane, n_drop);
+                if (single) {
+                    if constexpr (VISIT) {
+                        lds_store(&run_a[pos], 0xFFFFFFFFu);
+                        lds_store(&run_b[pos], (uint32_t)(c * LP + gl));
+                    } else {
+                        lds_store(&run_a[pos], xg[c]);
+                        if constexpr (THIS_UNIT) lds_store(&run_b[pos], __float_as_uint(converted_arg<ARG_UNIT, ARITH>(vg[c])));
+                    }
+                }
+                singles += n_single;
+                dropped += n_drop;
+            }
+        }
+        // the run leaves the wave: 256 contiguous bytes per store
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t t = lane; t < run_len; t += 64) {
+            out_ids[run_base + t] = (int32_t)lds_load(&run_a[t]);
+            if constexpr (SECOND) reinterpret_cast<uint32_t*>(out_data)[run_base + t] = lds_load(&run_b[t]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 struct Args {
     const sdrb_batch* a;
     const sdrb_batch* b;
@@ -521,6 +745,7 @@ struct Args {
     uint32_t nw, qc, cap_a, cap_b, rows_per_wave;
     bool visit;
     bool short_rows;   // both batches hold rows of at most kShortCap elements: k_elem_rank_short
+    bool runs;         // ... and the tables are small: k_elem_rank_runs (results leave as coalesced runs)
     dim3 grid;
     size_t lds;
     hipStream_t stream;
@@ -528,6 +753,18 @@ struct Args {
 
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false, bool ARITH = false>
 void launch(const Args& g) {
+    if (g.runs) {
+        const uint32_t longest = g.a->max_row_len > g.b->max_row_len ? g.a->max_row_len : g.b->max_row_len;
+        if (longest <= 48)
+            hipLaunchKernelGGL((k_elem_rank_runs<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 3>), g.grid, dim3(kBlock), g.lds,
+                               g.stream, g.a->d_offsets, g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets,
+                               g.b->d_ids, g.b->d_data, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc);
+        else
+            hipLaunchKernelGGL((k_elem_rank_runs<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 4>), g.grid, dim3(kBlock), g.lds,
+                               g.stream, g.a->d_offsets, g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets,
+                               g.b->d_ids, g.b->d_data, (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc);
+        return;
+    }
     if (g.short_rows) {
         const uint32_t longest = g.a->max_row_len > g.b->max_row_len ? g.a->max_row_len : g.b->max_row_len;
         if (longest <= 48)
@@ -583,13 +820,21 @@ constexpr size_t kMaxTableBytes = 512u << 20;  // tables of A in global memory
 constexpr size_t kLdsWanted = 64 * 1024;       // rows of A per block are halved until a block fits this
 constexpr size_t kLdsLimit = 64 * 1024;        // what a block may use at most
 constexpr size_t kLdsShortWanted = 40 * 1024;  // short-row kernel: four blocks per compute unit
+constexpr size_t kLdsRunsLimit = 52 * 1024;    // coalesced-run kernel: three blocks per compute unit
 
 struct Shape {
     uint32_t nw, qc, cap_a, cap_b;
     size_t lds;
     bool ok;
     bool short_rows;
+    bool runs;
 };
+
+size_t lds_bytes_runs(uint32_t nw, uint32_t qc) {
+    const size_t per_wave_words = (size_t)kRunRows * nw * 2 + (size_t)kRunRows * kShortCap * 2 + (size_t)(kRunRows + 1) * qc +
+                                  2 * (size_t)kRunStage;
+    return (size_t)qc * nw * sizeof(RankEntry) + (size_t)qc * kShortCap * 8 + (size_t)kWaves * per_wave_words * 4;
+}
 
 size_t lds_bytes_short(uint32_t nw, uint32_t qc) {
     return ((size_t)kWaves * nw + (size_t)qc * nw) * sizeof(RankEntry) + (size_t)qc * kShortCap * 8 +
@@ -612,6 +857,13 @@ Shape shape_for(const sdrb_batch* a, const sdrb_batch* b) {
     s.qc = kQueryChunk;
     // short rows on both sides and enough rows of A to fill the four lane groups: the short-row kernel
     s.short_rows = a->max_row_len <= (uint32_t)kShortCap && b->max_row_len <= (uint32_t)kShortCap && a->n_rows >= 4;
+    s.runs = false;
+    if (s.short_rows && lds_bytes_runs(s.nw, kQueryChunk) <= kLdsRunsLimit) {   // small tables: coalesced runs
+        s.runs = true;
+        s.lds = lds_bytes_runs(s.nw, s.qc);
+        s.ok = true;
+        return s;
+    }
     if (s.short_rows) {
         while (s.qc > 4 && lds_bytes_short(s.nw, s.qc) > kLdsShortWanted) s.qc >>= 1;
         s.lds = lds_bytes_short(s.nw, s.qc);
@@ -659,6 +911,7 @@ int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
     g.out_data = out_data;
     g.visit = visit;
     g.short_rows = shape.short_rows;
+    g.runs = shape.runs;
     g.nw = nw;
     g.qc = shape.qc;
     g.cap_a = shape.cap_a;
@@ -670,6 +923,7 @@ int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
     const uint64_t ychunks = (a->n_rows + g.qc - 1) / g.qc;
     uint32_t rpw = shape.short_rows ? (uint32_t)kShortRows : 16u;
     while (rpw > 1 && (nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves) * ychunks < 4096) rpw >>= 1;
+    if (shape.runs) rpw = (uint32_t)kRunRows;   // every wave takes exactly the rows of one turn
     g.rows_per_wave = rpw;
     g.grid = dim3((uint32_t)((nb + (uint64_t)rpw * kWaves - 1) / ((uint64_t)rpw * kWaves)), (uint32_t)ychunks);
     switch (op) {
