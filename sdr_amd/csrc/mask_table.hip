@@ -9,11 +9,15 @@
 //
 // and streams rows of B, one wave per row, one lane per element: a lane looks up mask[id] and
 // visits its set bits -- each one is an id match of the pair (q, j).  The payload of A for that
-// match comes from a dense value matrix val[q][w] (global, L2-resident, built per call), the
+// match comes from a column-compressed copy of the tile's payloads in LDS (col[w] = where the
+// payloads of id w start, in ascending row order -- the order the set bits are visited in) when
+// that fits, else from a dense value matrix val[q][w] (global, L2-resident, built per call); the
 // payload rule of the op is evaluated (single IEEE operations, sdrb_device.h) and the pair's
 // counters in LDS get  (1 << 16) | kept  added.  After 64 rows of B the 64 x 64 counter tile is
 // turned into sizes and written as coalesced rows.  B is read once per 64 rows of A instead of
 // once per row; the table is rebuilt only when the block moves to another tile of A.
+// The counter of pair (q, jl) lives at cnt[jl * 65 + q]: the lanes of a wave work on one jl and
+// different q, and the write-out reads one q and 64 jl -- both land in 64 different banks.
 #include "sdrb_device.h"
 #include "sdrb_internal.h"
 
@@ -26,6 +30,8 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kGroup = 64;                       // rows of B per counter tile
 constexpr int kRowsPerWave = kGroup / kWaves;    // 4
 constexpr int kTile = 64;                        // rows of A per mask table
+constexpr int kCntLd = kTile + 1;                // counter tile: [jl][q], padded against bank conflicts
+constexpr int kCntSize = kGroup * kCntLd;
 
 // How a match's payload decides whether it is kept; `t` is the payload of `this`
 // (same classification as unit_table.hip).
@@ -70,29 +76,33 @@ __global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restric
 // FILL == false: size ops (counters -> sizes).  FILL == true: ande -- the counter tile starts at the
 // pairs' output offsets and every kept match takes the next slot of its pair; slots of one pair are
 // claimed by concurrent lanes, so a pair's elements are put in id order afterwards (k_sort_pairs).
-template <int MATH, int NIT, bool FILL>
+template <int MATH, int NIT, bool FILL, bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val_dense,
     uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
     const float* __restrict__ b_data, uint32_t nb, uint32_t width, int op, uint32_t swap,
     uint32_t* __restrict__ out, uint64_t ld_out, const uint32_t* __restrict__ out_off,
-    int32_t* __restrict__ out_ids, float* __restrict__ out_data) {
+    int32_t* __restrict__ out_ids, float* __restrict__ out_data, const float* __restrict__ a_val,
+    uint32_t val_cap) {
     constexpr bool NEED_A = MATH == kSelfA || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr int IT = NIT == 0 ? 1 : NIT;
-    // LDS: mask[width + 1] (mask[width] = 0, the sentinel), cnt[64][64], la[64], lb[64]
+    // LDS: mask[width + 1] (mask[width] = 0, the sentinel), cnt[64][65], la[64], lb[64],
+    //      and with FLAT vals[val_cap], col[width + 1]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(mask + width + 1);
-    uint32_t* la = cnt + kTile * kGroup;
+    uint32_t* la = cnt + kCntSize;
     uint32_t* lb = la + kTile;
+    float* vals = reinterpret_cast<float*>(lb + kGroup);
+    uint16_t* col = reinterpret_cast<uint16_t*>(vals + val_cap);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile = blockIdx.y, i0 = tile * kTile;
     const uint32_t rows_a = na - i0 < (uint32_t)kTile ? na - i0 : (uint32_t)kTile;
 
     for (uint32_t w = tid; w < width + 1; w += kBlock) mask[w] = 0;
-    for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) cnt[e] = 0;
+    for (uint32_t e = tid; e < kCntSize; e += kBlock) cnt[e] = 0;
     if (tid < kTile) la[tid] = tid < rows_a ? a_off[i0 + tid + 1] - a_off[i0 + tid] : 0u;
     __syncthreads();
     // wave w sets the bits of rows w, w + 16, ... of the tile
@@ -104,121 +114,218 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
         }
     }
     __syncthreads();
+    if constexpr (FLAT && NEED_A) {
+        // col[w] = number of tile elements with an id below w: every thread counts a contiguous piece
+        // of the table, the pieces' totals are scanned over the block (lb[] holds the waves' totals)
+        const uint32_t per = (width + kBlock) / kBlock;
+        const uint32_t w0 = tid * per < width + 1 ? tid * per : width + 1;
+        const uint32_t w1 = w0 + per < width + 1 ? w0 + per : width + 1;
+        uint32_t mine = 0;
+        for (uint32_t w = w0; w < w1; ++w) mine += (uint32_t)__builtin_popcountll(mask[w]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) lb[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) run += lb[w];
+        for (uint32_t w = w0; w < w1; ++w) {
+            col[w] = (uint16_t)run;
+            run += (uint32_t)__builtin_popcountll(mask[w]);
+        }
+        __syncthreads();
+        for (uint32_t q = wave; q < rows_a; q += kWaves) {
+            const uint32_t beg = a_off[i0 + q], len = a_off[i0 + q + 1] - beg;
+            for (uint32_t k = lane; k < len; k += 64) {
+                const uint32_t id = (uint32_t)a_ids[beg + k];
+                if (id < width)
+                    vals[col[id] + (uint32_t)__builtin_popcountll(mask[id] & ((1ull << q) - 1ull))] = a_val[beg + k];
+            }
+        }
+        __syncthreads();
+    }
 
-    const float* val_tile = NEED_A ? a_val_dense + (uint64_t)i0 * width : nullptr;
+    const float* val_tile = NEED_A && !FLAT ? a_val_dense + (uint64_t)i0 * width : nullptr;
     const uint32_t n_groups = (nb + kGroup - 1) / kGroup;
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t j0 = g * kGroup;
         if constexpr (FILL) {   // the tile of output positions of this group's pairs
             for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) {
                 const uint32_t q = e / kGroup, jl = e % kGroup;
-                if (q < rows_a && j0 + jl < nb) cnt[e] = out_off[(uint64_t)(i0 + q) * nb + j0 + jl];
+                if (q < rows_a && j0 + jl < nb) cnt[jl * kCntLd + q] = out_off[(uint64_t)(i0 + q) * nb + j0 + jl];
             }
             __syncthreads();
         }
-        // Rows of up to 64*NIT elements travel HBM -> registers whole (bounds-checked buffer loads, all
-        // chunks issued back to back), and the next row is requested before the current one is
-        // processed, so a wave keeps two rows in flight; NIT == 0 streams longer rows chunk by chunk.
-        uint32_t cur_id[IT], nxt_id[IT];
-        float cur_v[IT], nxt_v[IT];
-        uint32_t cur_len = 0, nxt_len = 0;
-        auto request = [&](uint32_t jl, uint32_t (&rid)[IT], float (&rv)[IT], uint32_t& rlen) {
-            const uint32_t j = j0 + jl;
-            const uint32_t beg = j < nb ? b_off[j] : 0u;
-            rlen = j < nb ? b_off[j + 1] - beg : 0u;
-            if constexpr (NIT > 0) {
-                __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<int32_t*>(b_ids) + beg, 0, (int)(rlen * 4u), 0x00020000);
-                __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(b_data) + (NEED_B ? beg : 0u), 0, NEED_B ? (int)(rlen * 4u) : 0, 0x00020000);
+        if constexpr (FLAT) {
+            // The four rows of a wave are one contiguous piece of B's element arrays: its elements are
+            // dealt to the lanes two lanes each (one per 32-bit half of the mask), whatever row they
+            // belong to, so every lane has work and a lane's bit loop is short.
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kRowsPerWave));
+            uint32_t edge[kRowsPerWave + 1];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const uint32_t e = it * 64 + lane;
-                    rid[it] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ids_rsrc, (int)(e * 4u), 0, 0);
-                    rv[it] = 0.0f;
-                    if constexpr (NEED_B)
-                        rv[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, (int)(e * 4u), 0, 0));
-                }
+            for (int r = 0; r <= kRowsPerWave; ++r) {
+                const uint32_t j = j0 + r0 + r;
+                edge[r] = b_off[j < nb ? j : nb];
             }
-        };
-        auto visit = [&](uint32_t id, float vb, uint32_t jl) {
-            unsigned long long m = mask[id];
-            // every set bit is an id match of pair (q, j); four at a time so that the payload
-            // gathers of a lane (L2 latency) are in flight together
-            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-                uint32_t q[4];
-                bool has[4];
-                float va[4];
+            if (lane < (uint32_t)kRowsPerWave) {
+                uint32_t len = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    has[u] = m != 0;
-                    q[u] = has[u] ? (uint32_t)__builtin_ctzll(m) : 0u;
-                    m &= m - 1;
+                for (int r = 0; r < kRowsPerWave; ++r)
+                    if (lane == (uint32_t)r) len = edge[r + 1] - edge[r];
+                lb[r0 + lane] = len;
+            }
+            const uint32_t beg = edge[0], n = edge[kRowsPerWave] - edge[0];
+            const uint32_t half = lane & 1u;
+            auto fetch = [&](uint32_t s0, uint32_t& id, float& vb) {
+                const uint32_t e = (s0 + lane) >> 1;
+                id = width;
+                vb = 0.0f;
+                if (e < n) {
+                    id = (uint32_t)b_ids[beg + e];
+                    if constexpr (NEED_B) vb = b_data[beg + e];
                 }
+            };
+            uint32_t id, nxt_id = width;
+            float vb, nxt_vb = 0.0f;
+            fetch(0, id, vb);
+#pragma unroll 1
+            for (uint32_t s0 = 0; s0 < 2 * n; s0 += 64) {
+                if (s0 + 64 < 2 * n) fetch(s0 + 64, nxt_id, nxt_vb);
+                const uint32_t e = (s0 + lane) >> 1;
+                uint32_t jl = r0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    va[u] = 0.0f;
-                    if constexpr (NEED_A) {
-                        if (has[u]) va[u] = val_tile[(uint64_t)q[u] * width + id];
+                for (int r = 1; r < kRowsPerWave; ++r) jl += e >= edge[r] - beg ? 1u : 0u;
+                const uint2 both = *reinterpret_cast<const uint2*>(&mask[id]);
+                uint32_t m = half ? both.y : both.x;
+                uint32_t at = 0;   // where the payload of the next set bit is (set bits = ascending rows)
+                if constexpr (NEED_A) at = (uint32_t)col[id] + (half ? (uint32_t)__builtin_popcount(both.x) : 0u);
+                uint32_t* pair_cnt = cnt + jl * kCntLd + half * 32u;
+                while (m != 0) {
+                    const uint32_t q = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    float va = 0.0f;
+                    if constexpr (NEED_A) va = vals[at++];
+                    float d;
+                    const bool kept = match_kept_by<MATH>(va, vb, d);
+                    if constexpr (!FILL) {
+                        atomicAdd(&pair_cnt[q], 0x10000u | (kept ? 1u : 0u));
+                    } else if (kept) {
+                        const uint32_t slot = atomicAdd(&pair_cnt[q], 1u);
+                        out_ids[slot] = (int32_t)id;
+                        if constexpr (MATH != kKeepAll) out_data[slot] = d;
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (has[u]) {
-                        float d;
-                        const bool kept = match_kept_by<MATH>(va[u], vb, d);
-                        if constexpr (!FILL) {
-                            atomicAdd(&cnt[q[u] * kGroup + jl], 0x10000u | (kept ? 1u : 0u));
-                        } else if (kept) {
-                            const uint32_t slot = atomicAdd(&cnt[q[u] * kGroup + jl], 1u);
-                            out_ids[slot] = (int32_t)id;
-                            if constexpr (MATH != kKeepAll) out_data[slot] = d;
+                id = nxt_id;
+                vb = nxt_vb;
+            }
+        } else {
+            // Rows of up to 64*NIT elements travel HBM -> registers whole (bounds-checked buffer loads, all
+            // chunks issued back to back), and the next row is requested before the current one is
+            // processed, so a wave keeps two rows in flight; NIT == 0 streams longer rows chunk by chunk.
+            uint32_t cur_id[IT], nxt_id[IT];
+            float cur_v[IT], nxt_v[IT];
+            uint32_t cur_len = 0, nxt_len = 0;
+            auto request = [&](uint32_t jl, uint32_t (&rid)[IT], float (&rv)[IT], uint32_t& rlen) {
+                const uint32_t j = j0 + jl;
+                const uint32_t beg = j < nb ? b_off[j] : 0u;
+                rlen = j < nb ? b_off[j + 1] - beg : 0u;
+                if constexpr (NIT > 0) {
+                    __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<int32_t*>(b_ids) + beg, 0, (int)(rlen * 4u), 0x00020000);
+                    __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(b_data) + (NEED_B ? beg : 0u), 0, NEED_B ? (int)(rlen * 4u) : 0, 0x00020000);
+    #pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const uint32_t e = it * 64 + lane;
+                        rid[it] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ids_rsrc, (int)(e * 4u), 0, 0);
+                        rv[it] = 0.0f;
+                        if constexpr (NEED_B)
+                            rv[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, (int)(e * 4u), 0, 0));
+                    }
+                }
+            };
+            auto visit = [&](uint32_t id, float vb, uint32_t jl) {
+                unsigned long long m = mask[id];
+                    // every set bit is an id match of pair (q, j); four at a time so that the payload
+                // gathers of a lane are in flight together
+                while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+                    uint32_t q[4];
+                    bool has[4];
+                    float va[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        has[u] = m != 0;
+                        q[u] = has[u] ? (uint32_t)__builtin_ctzll(m) : 0u;
+                        m &= m - 1;
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        va[u] = 0.0f;
+                        if constexpr (NEED_A) {
+                            if (has[u]) va[u] = val_tile[(uint64_t)q[u] * width + id];
+                        }
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (has[u]) {
+                            float d;
+                            const bool kept = match_kept_by<MATH>(va[u], vb, d);
+                            if constexpr (!FILL) {
+                                atomicAdd(&cnt[jl * kCntLd + q[u]], 0x10000u | (kept ? 1u : 0u));
+                            } else if (kept) {
+                                const uint32_t slot = atomicAdd(&cnt[jl * kCntLd + q[u]], 1u);
+                                out_ids[slot] = (int32_t)id;
+                                if constexpr (MATH != kKeepAll) out_data[slot] = d;
+                            }
                         }
                     }
                 }
-            }
-        };
-        request(wave * kRowsPerWave, cur_id, cur_v, cur_len);
-#pragma unroll 1
-        for (int r = 0; r < kRowsPerWave; ++r) {
-            const uint32_t jl = wave * kRowsPerWave + r;
-            if (r + 1 < kRowsPerWave) request(jl + 1, nxt_id, nxt_v, nxt_len);
-            if (lane == 0) lb[jl] = cur_len;
-            if constexpr (NIT > 0) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    // lanes past the row's end read nothing: give them the sentinel id (mask 0)
-                    const uint32_t id = (uint32_t)(it * 64) + lane < cur_len ? cur_id[it] : width;
-                    if ((uint32_t)(it * 64) < cur_len) visit(id, cur_v[it], jl);
-                }
-            } else {
-                const uint32_t j = j0 + jl;
-                const uint32_t beg = j < nb ? b_off[j] : 0u;
-                for (uint32_t e0 = 0; e0 < cur_len; e0 += 64) {
-                    const uint32_t e = e0 + lane;
-                    uint32_t id = width;
-                    float vb = 0.0f;
-                    if (e < cur_len) {
-                        id = (uint32_t)b_ids[beg + e];
-                        if constexpr (NEED_B) vb = b_data[beg + e];
+            };
+            request(wave * kRowsPerWave, cur_id, cur_v, cur_len);
+    #pragma unroll 1
+            for (int r = 0; r < kRowsPerWave; ++r) {
+                const uint32_t jl = wave * kRowsPerWave + r;
+                if (r + 1 < kRowsPerWave) request(jl + 1, nxt_id, nxt_v, nxt_len);
+                if (lane == 0) lb[jl] = cur_len;
+                if constexpr (NIT > 0) {
+    #pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        // lanes past the row's end read nothing: give them the sentinel id (mask 0)
+                        const uint32_t id = (uint32_t)(it * 64) + lane < cur_len ? cur_id[it] : width;
+                        if ((uint32_t)(it * 64) < cur_len) visit(id, cur_v[it], jl);
                     }
-                    visit(id, vb, jl);
+                } else {
+                    const uint32_t j = j0 + jl;
+                    const uint32_t beg = j < nb ? b_off[j] : 0u;
+                    for (uint32_t e0 = 0; e0 < cur_len; e0 += 64) {
+                        const uint32_t e = e0 + lane;
+                        uint32_t id = width;
+                        float vb = 0.0f;
+                        if (e < cur_len) {
+                            id = (uint32_t)b_ids[beg + e];
+                            if constexpr (NEED_B) vb = b_data[beg + e];
+                        }
+                        visit(id, vb, jl);
+                    }
                 }
+    #pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    cur_id[it] = nxt_id[it];
+                    cur_v[it] = nxt_v[it];
+                }
+                cur_len = nxt_len;
             }
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                cur_id[it] = nxt_id[it];
-                cur_v[it] = nxt_v[it];
-            }
-            cur_len = nxt_len;
         }
         __syncthreads();
         // counters -> sizes, one coalesced 256-byte row segment per wave instruction; reset the tile
         for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) {
             if constexpr (FILL) break;
             const uint32_t q = e / kGroup, jl = e % kGroup;
-            const uint32_t c = cnt[e];
-            cnt[e] = 0;
+            const uint32_t c = cnt[jl * kCntLd + q];
+            cnt[jl * kCntLd + q] = 0;
             if (q < rows_a && j0 + jl < nb) {
                 const uint32_t l_this = swap ? lb[jl] : la[q], l_arg = swap ? la[q] : lb[jl];
                 out[(uint64_t)(i0 + q) * ld_out + j0 + jl] = size_of(op, l_this, l_arg, c >> 16, c & 0xffffu);
@@ -262,7 +369,12 @@ int pick_math(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
 }
 
 size_t lds_bytes(uint32_t width) {
-    return (size_t)(width + 1) * 8 + (size_t)kTile * kGroup * 4 + 2 * kTile * 4;
+    return (size_t)(width + 1) * 8 + (size_t)kCntSize * 4 + (kTile + kGroup) * 4;
+}
+
+// with the tile's payloads in LDS: val_cap floats and a 16-bit column start per table entry
+size_t lds_bytes_vals(uint32_t width, uint32_t val_cap) {
+    return lds_bytes(width) + (size_t)val_cap * 4 + (size_t)(width + 2) * 2;
 }
 
 }  // namespace
@@ -280,8 +392,17 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     const uint32_t width = (uint32_t)b->width, na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
     const int math = pick_math(a, b, op, swap);
     const bool need_a = math == kSelfA || math == kMul || math == kAbsDiff || math == kRmulA || math == kRmulB;
+    // the tile's payloads in LDS when they fit
+    uint32_t val_cap = 0;
+    if (need_a && a->max_row_len < 1024) {
+        const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
+        val_cap = (uint32_t)kTile * (longest ? longest : 1u);
+        if (lds_bytes_vals(width, val_cap) > 160 * 1024 - 512) val_cap = 0;
+    }
+    // flat: B's elements dealt to lanes regardless of rows; needs the payloads of A (if any) in LDS
+    const bool flat = !need_a || val_cap != 0;
     float* dense = nullptr;
-    if (need_a) {
+    if (need_a && !flat) {
         const size_t bytes = (size_t)na * width * sizeof(float);
         dense = static_cast<float*>(workspace(b->device, 6, bytes));
         if (!dense) return SDRB_ERR_HIP;
@@ -290,7 +411,7 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
                            dense);
         SDRB_HIP(hipGetLastError());
     }
-    const size_t lds = lds_bytes(width);
+    const size_t lds = val_cap ? lds_bytes_vals(width, val_cap) : lds_bytes(width);
     const uint32_t tiles = (na + kTile - 1) / kTile;
     const uint32_t groups = (nb + kGroup - 1) / kGroup;
     // one or two resident blocks per CU, shared among the tiles of A
@@ -301,22 +422,25 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     const dim3 grid(gx, tiles);
     const uint32_t len = b->max_row_len;
     const int nit = len <= 64 ? 1 : len <= 128 ? 2 : len <= 384 ? 6 : 0;
-#define SDRB_MT_LAUNCH_NF(M, N, F)                                                                                   \
+#define SDRB_MT_LAUNCH_NFL(M, N, F, L)                                                                               \
     do {                                                                                                             \
-        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_size_mask_table<M, N, F>),                     \
+        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_size_mask_table<M, N, F, L>),                  \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((k_size_mask_table<M, N, F>), grid, dim3(kBlock), lds, stream, a->d_offsets, a->d_ids,    \
+        hipLaunchKernelGGL((k_size_mask_table<M, N, F, L>), grid, dim3(kBlock), lds, stream, a->d_offsets, a->d_ids, \
                            dense, na, b->d_offsets, b->d_ids, b->d_data, nb, width, op, swap ? 1u : 0u, out, ld_out, \
-                           out_off, out_ids, out_data);                                                              \
+                           out_off, out_ids, out_data, a->d_data, val_cap);                                          \
     } while (0)
-#define SDRB_MT_LAUNCH_N(M, N)               \
-    do {                                     \
-        if (fill) SDRB_MT_LAUNCH_NF(M, N, true); \
-        else SDRB_MT_LAUNCH_NF(M, N, false); \
+#define SDRB_MT_LAUNCH_N(M, N)                          \
+    do {                                                \
+        if (fill) SDRB_MT_LAUNCH_NFL(M, N, true, false);  \
+        else SDRB_MT_LAUNCH_NFL(M, N, false, false);      \
     } while (0)
 #define SDRB_MT_LAUNCH(M)                          \
     do {                                           \
-        if (nit == 1) SDRB_MT_LAUNCH_N(M, 1);      \
+        if (flat) {                                \
+            if (fill) SDRB_MT_LAUNCH_NFL(M, 0, true, true);  \
+            else SDRB_MT_LAUNCH_NFL(M, 0, false, true);      \
+        } else if (nit == 1) SDRB_MT_LAUNCH_N(M, 1);      \
         else if (nit == 2) SDRB_MT_LAUNCH_N(M, 2); \
         else if (nit == 6) SDRB_MT_LAUNCH_N(M, 6); \
         else SDRB_MT_LAUNCH_N(M, 0);               \
@@ -333,7 +457,7 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     }
 #undef SDRB_MT_LAUNCH
 #undef SDRB_MT_LAUNCH_N
-#undef SDRB_MT_LAUNCH_NF
+#undef SDRB_MT_LAUNCH_NFL
     SDRB_HIP(hipGetLastError());
     if (fill) {
         const uint64_t pairs = (uint64_t)na * nb;
