@@ -18,6 +18,9 @@
 // once per row; the table is rebuilt only when the block moves to another tile of A.
 // The counter of pair (q, jl) lives at cnt[jl * 65 + q]: the lanes of a wave work on one jl and
 // different q, and the write-out reads one q and 64 jl -- both land in 64 different banks.
+#include <initializer_list>
+#include <type_traits>
+
 #include "sdrb_device.h"
 #include "sdrb_internal.h"
 
@@ -29,9 +32,9 @@ constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 constexpr int kGroup = 64;                       // rows of B per counter tile
 constexpr int kRowsPerWave = kGroup / kWaves;    // 4
-constexpr int kTile = 64;                        // rows of A per mask table
-constexpr int kCntLd = kTile + 1;                // counter tile: [jl][q], padded against bank conflicts
-constexpr int kCntSize = kGroup * kCntLd;
+// rows of A per mask table: 64, or 32 where that makes room for the tile's payloads in LDS;
+// counter tile: [row of B][row of A], padded by one word against bank conflicts
+constexpr int cnt_ld(int tile) { return tile + 1; }
 
 // How a match's payload decides whether it is kept; `t` is the payload of `this`
 // (same classification as unit_table.hip).
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restric
 // FILL == false: size ops (counters -> sizes).  FILL == true: ande -- the counter tile starts at the
 // pairs' output offsets and every kept match takes the next slot of its pair; slots of one pair are
 // claimed by concurrent lanes, so a pair's elements are put in id order afterwards (k_sort_pairs).
-template <int MATH, int NIT, bool FILL, bool FLAT>
+template <int MATH, int NIT, bool FILL, bool FLAT, int TILE>
 __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val_dense,
     uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
@@ -87,11 +90,14 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     constexpr bool NEED_A = MATH == kSelfA || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr int IT = NIT == 0 ? 1 : NIT;
-    // LDS: mask[width + 1] (mask[width] = 0, the sentinel), cnt[64][65], la[64], lb[64],
+    static_assert(TILE == 64 || (TILE == 32 && FLAT), "32-row tiles exist for the flat loop only");
+    using mask_t = std::conditional_t<TILE == 64, unsigned long long, uint32_t>;
+    constexpr int kTile = TILE, kCntLd = cnt_ld(TILE), kCntSize = kGroup * kCntLd;
+    // LDS: mask[width + 1] (mask[width] = 0, the sentinel), cnt[64][TILE + 1], la[TILE], lb[64],
     //      and with FLAT vals[val_cap], col[width + 1]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* mask = reinterpret_cast<unsigned long long*>(lds_raw);
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(mask + width + 1);
+    mask_t* mask = reinterpret_cast<mask_t*>(lds_raw);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(mask + width + 1 + ((width + 1) & 1u));
     uint32_t* la = cnt + kCntSize;
     uint32_t* lb = la + kTile;
     float* vals = reinterpret_cast<float*>(lb + kGroup);
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
         const uint32_t beg = a_off[i0 + q], len = a_off[i0 + q + 1] - beg;
         for (uint32_t k = lane; k < len; k += 64) {
             const uint32_t id = (uint32_t)a_ids[beg + k];
-            if (id < width) atomicOr(&mask[id], 1ull << q);   // ids outside B's width never match
+            if (id < width) atomicOr(&mask[id], (mask_t)1 << q);   // ids outside B's width never match
         }
     }
     __syncthreads();
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
         const uint32_t w0 = tid * per < width + 1 ? tid * per : width + 1;
         const uint32_t w1 = w0 + per < width + 1 ? w0 + per : width + 1;
         uint32_t mine = 0;
-        for (uint32_t w = w0; w < w1; ++w) mine += (uint32_t)__builtin_popcountll(mask[w]);
+        for (uint32_t w = w0; w < w1; ++w) mine += (uint32_t)__builtin_popcountll((unsigned long long)mask[w]);
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
         for (uint32_t w = 0; w < wave; ++w) run += lb[w];
         for (uint32_t w = w0; w < w1; ++w) {
             col[w] = (uint16_t)run;
-            run += (uint32_t)__builtin_popcountll(mask[w]);
+            run += (uint32_t)__builtin_popcountll((unsigned long long)mask[w]);
         }
         __syncthreads();
         for (uint32_t q = wave; q < rows_a; q += kWaves) {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
             for (uint32_t k = lane; k < len; k += 64) {
                 const uint32_t id = (uint32_t)a_ids[beg + k];
                 if (id < width)
-                    vals[col[id] + (uint32_t)__builtin_popcountll(mask[id] & ((1ull << q) - 1ull))] = a_val[beg + k];
+                    vals[col[id] + (uint32_t)__builtin_popcountll((unsigned long long)(mask[id] & (((mask_t)1 << q) - 1)))] = a_val[beg + k];
             }
         }
         __syncthreads();
@@ -161,8 +167,9 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
         }
         if constexpr (FLAT) {
             // The four rows of a wave are one contiguous piece of B's element arrays: its elements are
-            // dealt to the lanes two lanes each (one per 32-bit half of the mask), whatever row they
-            // belong to, so every lane has work and a lane's bit loop is short.
+            // dealt to the lanes, one lane per 32 bits of the mask (two lanes per element with 64-row
+            // tiles), whatever row they belong to, so every lane has work and a lane's bit loop is short.
+            constexpr uint32_t LPE = TILE / 32;   // lanes per element
             const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kRowsPerWave));
             uint32_t edge[kRowsPerWave + 1];
 #pragma unroll
@@ -178,9 +185,9 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                 lb[r0 + lane] = len;
             }
             const uint32_t beg = edge[0], n = edge[kRowsPerWave] - edge[0];
-            const uint32_t half = lane & 1u;
+            const uint32_t half = LPE == 2 ? lane & 1u : 0u;
             auto fetch = [&](uint32_t s0, uint32_t& id, float& vb) {
-                const uint32_t e = (s0 + lane) >> 1;
+                const uint32_t e = (s0 + lane) / LPE;
                 id = width;
                 vb = 0.0f;
                 if (e < n) {
@@ -191,17 +198,26 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
             uint32_t id, nxt_id = width;
             float vb, nxt_vb = 0.0f;
             fetch(0, id, vb);
+            // the first elements are waited for here, not inside the loop, where the wait would also
+            // cover the elements requested for the next turn
+            asm volatile("" : "+v"(id), "+v"(vb));
 #pragma unroll 1
-            for (uint32_t s0 = 0; s0 < 2 * n; s0 += 64) {
-                if (s0 + 64 < 2 * n) fetch(s0 + 64, nxt_id, nxt_vb);
-                const uint32_t e = (s0 + lane) >> 1;
+            for (uint32_t s0 = 0; s0 < LPE * n; s0 += 64) {
+                if (s0 + 64 < LPE * n) fetch(s0 + 64, nxt_id, nxt_vb);
+                const uint32_t e = (s0 + lane) / LPE;
                 uint32_t jl = r0;
 #pragma unroll
                 for (int r = 1; r < kRowsPerWave; ++r) jl += e >= edge[r] - beg ? 1u : 0u;
-                const uint2 both = *reinterpret_cast<const uint2*>(&mask[id]);
-                uint32_t m = half ? both.y : both.x;
+                uint32_t m, below = 0;   // below: set bits of the element's mask that other lanes visit first
+                if constexpr (LPE == 2) {
+                    const uint2 both = *reinterpret_cast<const uint2*>(&mask[id]);
+                    m = half ? both.y : both.x;
+                    below = half ? (uint32_t)__builtin_popcount(both.x) : 0u;
+                } else {
+                    m = (uint32_t)mask[id];
+                }
                 uint32_t at = 0;   // where the payload of the next set bit is (set bits = ascending rows)
-                if constexpr (NEED_A) at = (uint32_t)col[id] + (half ? (uint32_t)__builtin_popcount(both.x) : 0u);
+                if constexpr (NEED_A) at = (uint32_t)col[id] + below;
                 uint32_t* pair_cnt = cnt + jl * kCntLd + half * 32u;
                 while (m != 0) {
                     const uint32_t q = (uint32_t)__builtin_ctz(m);
@@ -368,13 +384,14 @@ int pick_math(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
     return swap ? kRmulB : kRmulA;
 }
 
-size_t lds_bytes(uint32_t width) {
-    return (size_t)(width + 1) * 8 + (size_t)kCntSize * 4 + (kTile + kGroup) * 4;
+size_t lds_bytes(uint32_t width, int tile = 64) {
+    const size_t entries = (size_t)(width + 1) + ((width + 1) & 1u);
+    return entries * (tile / 8) + (size_t)kGroup * cnt_ld(tile) * 4 + (tile + kGroup) * 4;
 }
 
 // with the tile's payloads in LDS: val_cap floats and a 16-bit column start per table entry
-size_t lds_bytes_vals(uint32_t width, uint32_t val_cap) {
-    return lds_bytes(width) + (size_t)val_cap * 4 + (size_t)(width + 2) * 2;
+size_t lds_bytes_vals(uint32_t width, uint32_t val_cap, int tile) {
+    return lds_bytes(width, tile) + (size_t)val_cap * 4 + (size_t)(width + 2) * 2;
 }
 
 }  // namespace
@@ -382,7 +399,7 @@ size_t lds_bytes_vals(uint32_t width, uint32_t val_cap) {
 bool mask_table_applicable(const sdrb_batch* a, const sdrb_batch* b) {
     // the mask table and the counter tile must fit the 160 KiB of LDS; counters hold row lengths in 16 bits
     return b->width > 0 && lds_bytes((uint32_t)b->width) <= 160 * 1024 - 512 && a->max_row_len < 65536 &&
-           b->max_row_len < 65536 && (a->n_rows + kTile - 1) / kTile <= 65535;
+           b->max_row_len < 65536 && (a->n_rows + 31) / 32 <= 65535;
 }
 
 namespace {
@@ -392,15 +409,24 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     const uint32_t width = (uint32_t)b->width, na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
     const int math = pick_math(a, b, op, swap);
     const bool need_a = math == kSelfA || math == kMul || math == kAbsDiff || math == kRmulA || math == kRmulB;
-    // the tile's payloads in LDS when they fit
+    // the tile's payloads in LDS when they fit beside a 64-row table, else beside a 32-row table
     uint32_t val_cap = 0;
+    int tile = 64;
     if (need_a && a->max_row_len < 1024) {
         const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
-        val_cap = (uint32_t)kTile * (longest ? longest : 1u);
-        if (lds_bytes_vals(width, val_cap) > 160 * 1024 - 512) val_cap = 0;
+        for (int t : {64, 32}) {
+            const uint32_t cap = (uint32_t)t * (longest ? longest : 1u);
+            if (lds_bytes_vals(width, cap, t) <= 160 * 1024 - 512) {
+                val_cap = cap;
+                tile = t;
+                break;
+            }
+        }
     }
-    // flat: B's elements dealt to lanes regardless of rows; needs the payloads of A (if any) in LDS
-    const bool flat = !need_a || val_cap != 0;
+    // flat: B's elements dealt to lanes regardless of rows; needs the payloads of A (if any) in LDS.
+    // Without payloads of A it pays where two blocks share a compute unit; with one block (wide
+    // tables) whole rows prefetched into registers hide the latency better.
+    const bool flat = need_a ? val_cap != 0 : lds_bytes(width) <= 80 * 1024 - 256;
     float* dense = nullptr;
     if (need_a && !flat) {
         const size_t bytes = (size_t)na * width * sizeof(float);
@@ -411,8 +437,8 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
                            dense);
         SDRB_HIP(hipGetLastError());
     }
-    const size_t lds = val_cap ? lds_bytes_vals(width, val_cap) : lds_bytes(width);
-    const uint32_t tiles = (na + kTile - 1) / kTile;
+    const size_t lds = val_cap ? lds_bytes_vals(width, val_cap, tile) : lds_bytes(width);
+    const uint32_t tiles = (na + tile - 1) / tile;
     const uint32_t groups = (nb + kGroup - 1) / kGroup;
     // one or two resident blocks per CU, shared among the tiles of A
     const uint32_t per_cu = lds <= 80 * 1024 - 256 ? 2u : 1u;
@@ -422,24 +448,28 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     const dim3 grid(gx, tiles);
     const uint32_t len = b->max_row_len;
     const int nit = len <= 64 ? 1 : len <= 128 ? 2 : len <= 384 ? 6 : 0;
-#define SDRB_MT_LAUNCH_NFL(M, N, F, L)                                                                               \
+#define SDRB_MT_LAUNCH_NFL(M, N, F, L, T)                                                                             \
     do {                                                                                                             \
-        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_size_mask_table<M, N, F, L>),                  \
+        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_size_mask_table<M, N, F, L, T>),               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((k_size_mask_table<M, N, F, L>), grid, dim3(kBlock), lds, stream, a->d_offsets, a->d_ids, \
+        hipLaunchKernelGGL((k_size_mask_table<M, N, F, L, T>), grid, dim3(kBlock), lds, stream, a->d_offsets,        \
+                           a->d_ids,                                                                                \
                            dense, na, b->d_offsets, b->d_ids, b->d_data, nb, width, op, swap ? 1u : 0u, out, ld_out, \
                            out_off, out_ids, out_data, a->d_data, val_cap);                                          \
     } while (0)
 #define SDRB_MT_LAUNCH_N(M, N)                          \
     do {                                                \
-        if (fill) SDRB_MT_LAUNCH_NFL(M, N, true, false);  \
-        else SDRB_MT_LAUNCH_NFL(M, N, false, false);      \
+        if (fill) SDRB_MT_LAUNCH_NFL(M, N, true, false, 64);  \
+        else SDRB_MT_LAUNCH_NFL(M, N, false, false, 64);      \
     } while (0)
 #define SDRB_MT_LAUNCH(M)                          \
     do {                                           \
-        if (flat) {                                \
-            if (fill) SDRB_MT_LAUNCH_NFL(M, 0, true, true);  \
-            else SDRB_MT_LAUNCH_NFL(M, 0, false, true);      \
+        if (flat && tile == 32) {                  \
+            if (fill) SDRB_MT_LAUNCH_NFL(M, 0, true, true, 32);  \
+            else SDRB_MT_LAUNCH_NFL(M, 0, false, true, 32);      \
+        } else if (flat) {                         \
+            if (fill) SDRB_MT_LAUNCH_NFL(M, 0, true, true, 64);  \
+            else SDRB_MT_LAUNCH_NFL(M, 0, false, true, 64);      \
         } else if (nit == 1) SDRB_MT_LAUNCH_N(M, 1);      \
         else if (nit == 2) SDRB_MT_LAUNCH_N(M, 2); \
         else if (nit == 6) SDRB_MT_LAUNCH_N(M, 6); \
