@@ -468,14 +468,17 @@ def test_rowwise_needs_equal_lengths():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(PAIRINGS))
-def test_mask_table_kernel_many_tiles_and_groups(name):
-    """The 64-row mask-table kernel over several tiles of A (partial last tile), several 64-row
-    groups of B (partial last group) and rows of several 64-element chunks."""
+@pytest.mark.parametrize("width,max_len", [(16384, 328), (2048, 40), (9000, 200), (40000, 90)])
+def test_mask_table_kernel_many_tiles_and_groups(name, width, max_len):
+    """The mask-table kernel over several tiles of A (partial last tile), several 64-row groups of B
+    (partial last group) and rows of several 64-element chunks; the shapes pick its variants: 32-row
+    tiles with the payloads of A in LDS, 64-row tiles with them, and (width 40000: too wide for the
+    table) the fallback."""
     tu, au = PAIRINGS[name]
-    rng = np.random.default_rng(99 + 2 * tu + au)
-    t = Batch(*util.ragged_rows(rng, 150, 16384, 328, tu))
-    a = Batch(*util.ragged_rows(rng, 333, 16384, 328, au))
-    dt, da = dev(t, 16384), dev(a, 16384)
+    rng = np.random.default_rng(99 + 2 * tu + au + width)
+    t = Batch(*util.ragged_rows(rng, 150, width, max_len, tu))
+    a = Batch(*util.ragged_rows(rng, 333, width, max_len, au))
+    dt, da = dev(t, width), dev(a, width)
     for op in range(4):
         want = oracle.port().size_op(op, t, a)
         assert np.array_equal(gpu_sizes(op, dt, da), want), op
