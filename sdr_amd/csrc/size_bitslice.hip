@@ -121,9 +121,17 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_b
         const_cast<int32_t*>(b_ids) + blk_beg, 0, (int)((blk_end - blk_beg) * 4u), 0x00020000);
     const uint32_t rel = (beg - blk_beg) * 4u;
     uint32_t off[8 * NCH];
+    // four ids per load: a lane's row is contiguous, and with 16 bytes per lane the wave asks for
+    // each cache line four times instead of sixteen (dwords past the buffer's end read as zero
+    // one by one, so a row that ends at the end of the array is still read whole)
 #pragma unroll
-    for (int k = 0; k < 8 * NCH; ++k)
-        off[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ids_rsrc, (int)(rel + 4u * k), 0, 0);
+    for (int k4 = 0; k4 < 2 * NCH; ++k4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ids_rsrc, (int)(rel + 16u * k4), 0, 0);
+        off[4 * k4 + 0] = v[0];
+        off[4 * k4 + 1] = v[1];
+        off[4 * k4 + 2] = v[2];
+        off[4 * k4 + 3] = v[3];
+    }
 #pragma unroll
     for (int k = 0; k < 8 * NCH; ++k) off[k] = (uint32_t)k < lb ? off[k] * 8u : WCAP * 8u;
     const uint32_t lbterm = use_lb ? lb : 0u;
@@ -166,6 +174,77 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_b
             if (more) write_tile(pf, lds, tid);
         }
         __syncthreads();
+    }
+}
+
+// Up to eight rows of A (the one-query-against-a-database case): the table word of an id holds one
+// BYTE per row of A, 1 where the row contains the id, so a lane adds the 64-bit words of its ids
+// as two 32-bit sums and each byte ends up as a match count (rows of B hold at most 255 ids).
+// Every block builds the 8 * width bytes of table itself (A is a few hundred ids), so the whole
+// operation is one launch; blocks stride over the 256-row pieces of B.
+// MODE, use_la, use_lb as in k_size_bitslice.
+constexpr int kFewRows = 8;
+// NQ: a lane fetches its row as NQ loads of four ids, all issued before the first is used
+template <int MODE, int NQ>
+__global__ __launch_bounds__(kBlock) void k_size_few(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, uint32_t na,
+    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb, uint32_t width,
+    uint32_t use_la, uint32_t use_lb, uint32_t* __restrict__ out, uint64_t ld_out) {
+    extern __shared__ __attribute__((aligned(16))) u64 few_tab[];   // [width + 1], entry [width] stays zero
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t w = tid; w <= width; w += kBlock) few_tab[w] = 0;
+    __syncthreads();
+    for (uint32_t q = 0; q < na; ++q) {
+        const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+        for (uint32_t k = tid; k < len; k += kBlock) {
+            const uint32_t id = (uint32_t)a_ids[beg + k];
+            if (id < width) atomicOr(&few_tab[id], 1ull << (8 * q));   // ids outside B's width never match
+        }
+    }
+    __syncthreads();
+    uint32_t la[kFewRows];
+#pragma unroll
+    for (int q = 0; q < kFewRows; ++q) la[q] = (MODE != 0 && use_la && (uint32_t)q < na) ? a_off[q + 1] - a_off[q] : 0u;
+    const char* base = reinterpret_cast<const char*>(few_tab);
+    const uint64_t pieces = (nb + kBlock - 1) / kBlock;
+    for (uint64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
+        const uint64_t j0 = piece * kBlock, j = j0 + tid;
+        uint32_t beg = 0, lb = 0;
+        if (j < nb) {
+            beg = b_off[j];
+            lb = b_off[j + 1] - beg;
+        }
+        const uint32_t blk_beg = b_off[j0];                                   // uniform
+        const uint64_t blk_last = j0 + kBlock < nb ? j0 + kBlock : nb;
+        const uint32_t blk_end = b_off[blk_last];                             // uniform
+        __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int32_t*>(b_ids) + blk_beg, 0, (int)((blk_end - blk_beg) * 4u), 0x00020000);
+        const uint32_t rel = (beg - blk_beg) * 4u;
+        u32x4 ids[NQ];
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; ++k4)
+            ids[k4] = __builtin_amdgcn_raw_buffer_load_b128(ids_rsrc, (int)(rel + 16u * k4), 0, 0);
+        uint32_t sum_lo = 0, sum_hi = 0;
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; ++k4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t byte_off = (uint32_t)(4 * k4 + c) < lb ? ids[k4][c] * 8u : width * 8u;
+                const u64 w = *reinterpret_cast<const u64*>(base + byte_off);
+                sum_lo += (uint32_t)w;
+                sum_hi += (uint32_t)(w >> 32);
+            }
+        }
+        const uint32_t lbterm = (MODE != 0 && use_lb) ? lb : 0u;
+        uint32_t* dst = out + j;
+#pragma unroll
+        for (int q = 0; q < kFewRows; ++q) {
+            uint32_t v = ((q < 4 ? sum_lo : sum_hi) >> (8 * (q & 3))) & 0xffu;
+            if constexpr (MODE == 1) v = la[q] + lbterm - v;
+            if constexpr (MODE == 2) v = la[q] + lbterm - 2 * v;
+            if ((uint32_t)q < na && j < nb) __builtin_nontemporal_store(v, dst);
+            dst += ld_out;
+        }
     }
 }
 
@@ -233,6 +312,38 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
         return SDRB_ERR_UNSUPPORTED;
     }
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+
+    if (a->n_rows <= kFewRows) {
+        const uint32_t quads = (b->max_row_len + 3) / 4;   // <= 16: rows of B hold at most 64 ids here
+        const uint64_t pieces = ((uint64_t)b->n_rows + kBlock - 1) / kBlock;
+        const uint32_t grid = (uint32_t)(pieces < 2048 ? pieces : 2048);   // eight blocks per compute unit
+        const size_t lds = ((size_t)b->width + 1) * sizeof(u64);
+        const uint32_t use_la = op == SDRB_OP_AND ? 0u : op == SDRB_OP_RM ? (swap ? 0u : 1u) : 1u;
+        const uint32_t use_lb = op == SDRB_OP_AND ? 0u : op == SDRB_OP_RM ? (swap ? 1u : 0u) : 1u;
+#define SDRB_FEW_LAUNCH_N(M, N)                                                                                 \
+    hipLaunchKernelGGL((k_size_few<M, N>), dim3(grid), dim3(kBlock), lds, stream, a->d_offsets, a->d_ids,       \
+                       (uint32_t)a->n_rows, b->d_offsets, b->d_ids, (uint64_t)b->n_rows, (uint32_t)b->width,    \
+                       use_la, use_lb, out, ld_out)
+#define SDRB_FEW_LAUNCH(M)                          \
+    do {                                            \
+        if (quads <= 4) SDRB_FEW_LAUNCH_N(M, 4);    \
+        else if (quads <= 10) SDRB_FEW_LAUNCH_N(M, 10); \
+        else SDRB_FEW_LAUNCH_N(M, 16);              \
+    } while (0)
+        switch (op) {
+        case SDRB_OP_AND: SDRB_FEW_LAUNCH(0); break;
+        case SDRB_OP_OR:
+        case SDRB_OP_RM: SDRB_FEW_LAUNCH(1); break;
+        case SDRB_OP_XOR: SDRB_FEW_LAUNCH(2); break;
+        default:
+            set_error("unknown op %d", op);
+            return SDRB_ERR_INVALID_ARG;
+        }
+#undef SDRB_FEW_LAUNCH_N
+#undef SDRB_FEW_LAUNCH
+        SDRB_HIP(hipGetLastError());
+        return SDRB_OK;
+    }
 
     Args g;
     g.a = a;
