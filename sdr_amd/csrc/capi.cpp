@@ -707,7 +707,7 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         if (id_only(a, b, op, swap) && popcount_applicable(a, b))
             return launch_size_popcount(a, b, op, swap, out, ld_out, s);
         // payloads or long rows: with several rows of A the 64-row mask table reads B once for all of them
-        if (!(flags & SDRB_FLAG_FORCE_ROWTABLE) && a->n_rows >= 4 && mask_table_applicable(a, b))
+        if (!(flags & SDRB_FLAG_FORCE_ROWTABLE) && mask_table_applicable(a, b))
             return launch_size_mask_table(a, b, op, swap, out, ld_out, s);
         if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
     }

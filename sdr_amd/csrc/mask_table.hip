@@ -351,6 +351,141 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     }
 }
 
+// Up to eight rows of A against a database whose rows hold at most 64 ids (one query, or a handful,
+// with payloads): a lane owns a row of B, fetched with 16-byte loads that are all issued up front.
+// LDS holds one BYTE per id (bit q: row q of A contains it), the column starts and the
+// column-compressed payloads of A as in the flat loop above; a lane's match and kept counts of
+// the eight pairs are bytes of two 32-bit registers each.  One launch, B read once, no atomics.
+constexpr int kFewRows = 8;
+constexpr int kFewBlock = 256;
+template <int MATH, int NQ>
+__global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val,
+    uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
+    const float* __restrict__ b_data, uint64_t nb, uint32_t width, int op, uint32_t swap, uint32_t val_cap,
+    uint32_t* __restrict__ out, uint64_t ld_out) {
+    constexpr bool NEED_A = MATH == kSelfA || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
+    constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // LDS: vals[val_cap] | bits[(width + 4) / 4] (one byte per id, entry [width] stays zero) | col[width + 1]
+    extern __shared__ __attribute__((aligned(16))) unsigned char few_raw[];
+    float* vals = reinterpret_cast<float*>(few_raw);
+    uint32_t* bits32 = reinterpret_cast<uint32_t*>(vals + val_cap);
+    const unsigned char* bits = reinterpret_cast<const unsigned char*>(bits32);
+    const uint32_t words = (width + 4) / 4;
+    uint16_t* col = reinterpret_cast<uint16_t*>(bits32 + words);
+    __shared__ uint32_t wave_tot[kFewBlock / 64];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t w = tid; w < words; w += kFewBlock) bits32[w] = 0;
+    __syncthreads();
+    for (uint32_t q = 0; q < na; ++q) {
+        const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+        for (uint32_t k = tid; k < len; k += kFewBlock) {
+            const uint32_t id = (uint32_t)a_ids[beg + k];
+            if (id < width) atomicOr(&bits32[id >> 2], (1u << q) << (8 * (id & 3)));   // ids outside B's width never match
+        }
+    }
+    __syncthreads();
+    if constexpr (NEED_A) {
+        const uint32_t per = (width + kFewBlock) / kFewBlock;
+        const uint32_t w0 = tid * per < width + 1 ? tid * per : width + 1;
+        const uint32_t w1 = w0 + per < width + 1 ? w0 + per : width + 1;
+        uint32_t mine = 0;
+        for (uint32_t w = w0; w < w1; ++w) mine += (uint32_t)__builtin_popcount(bits[w]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) run += wave_tot[w];
+        for (uint32_t w = w0; w < w1; ++w) {
+            col[w] = (uint16_t)run;
+            run += (uint32_t)__builtin_popcount(bits[w]);
+        }
+        __syncthreads();
+        for (uint32_t q = 0; q < na; ++q) {
+            const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+            for (uint32_t k = tid; k < len; k += kFewBlock) {
+                const uint32_t id = (uint32_t)a_ids[beg + k];
+                if (id < width) vals[col[id] + (uint32_t)__builtin_popcount(bits[id] & ((1u << q) - 1u))] = a_val[beg + k];
+            }
+        }
+        __syncthreads();
+    }
+    uint32_t la[kFewRows];
+#pragma unroll
+    for (int q = 0; q < kFewRows; ++q) la[q] = (uint32_t)q < na ? a_off[q + 1] - a_off[q] : 0u;
+
+    const uint64_t pieces = (nb + kFewBlock - 1) / kFewBlock;
+    for (uint64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
+        const uint64_t j0 = piece * kFewBlock, j = j0 + tid;
+        uint32_t beg = 0, lb = 0;
+        if (j < nb) {
+            beg = b_off[j];
+            lb = b_off[j + 1] - beg;
+        }
+        const uint32_t blk_beg = b_off[j0];                                   // uniform
+        const uint64_t blk_last = j0 + kFewBlock < nb ? j0 + kFewBlock : nb;
+        const uint32_t blk_bytes = (b_off[blk_last] - blk_beg) * 4u;          // uniform
+        __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int32_t*>(b_ids) + blk_beg, 0, (int)blk_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(b_data) + (NEED_B ? blk_beg : 0u), 0, NEED_B ? (int)blk_bytes : 0, 0x00020000);
+        const uint32_t rel = (beg - blk_beg) * 4u;
+        u32x4 ids[NQ], vbs[NEED_B ? NQ : 1];
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; ++k4) {
+            ids[k4] = __builtin_amdgcn_raw_buffer_load_b128(ids_rsrc, (int)(rel + 16u * k4), 0, 0);
+            if constexpr (NEED_B) vbs[k4] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, (int)(rel + 16u * k4), 0, 0);
+        }
+        uint32_t m_lo = 0, m_hi = 0, k_lo = 0, k_hi = 0;   // bytes: matches / kept matches of pairs 0..3, 4..7
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; ++k4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t id = (uint32_t)(4 * k4 + c) < lb ? ids[k4][c] : width;
+                uint32_t m = bits[id];
+                if (m != 0) {
+                    float vb = 0.0f;
+                    if constexpr (NEED_B) vb = __builtin_bit_cast(float, (uint32_t)vbs[k4][c]);
+                    uint32_t at = 0;
+                    if constexpr (NEED_A) at = col[id];
+                    do {
+                        const uint32_t q = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        float va = 0.0f;
+                        if constexpr (NEED_A) va = vals[at++];
+                        float d;
+                        const uint32_t kept = match_kept_by<MATH>(va, vb, d) ? 1u : 0u;
+                        const uint32_t sh = 8 * (q & 3);
+                        if (q < 4) {
+                            m_lo += 1u << sh;
+                            k_lo += kept << sh;
+                        } else {
+                            m_hi += 1u << sh;
+                            k_hi += kept << sh;
+                        }
+                    } while (m != 0);
+                }
+            }
+        }
+        uint32_t* dst = out + j;
+#pragma unroll
+        for (int q = 0; q < kFewRows; ++q) {
+            const uint32_t mq = ((q < 4 ? m_lo : m_hi) >> (8 * (q & 3))) & 0xffu;
+            const uint32_t kq = ((q < 4 ? k_lo : k_hi) >> (8 * (q & 3))) & 0xffu;
+            const uint32_t l_this = swap ? lb : la[q], l_arg = swap ? la[q] : lb;
+            if ((uint32_t)q < na && j < nb) __builtin_nontemporal_store(size_of(op, l_this, l_arg, mq, kq), dst);
+            dst += ld_out;
+        }
+    }
+}
+
 // one thread per pair: insertion sort of the pair's few elements by id (payloads travel along)
 __global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__ off, uint64_t n_pairs,
                                                     int32_t* __restrict__ ids, float* __restrict__ data) {
@@ -500,9 +635,62 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
 
 }  // namespace
 
+namespace {
+
+size_t few_lds_bytes(uint32_t width, uint32_t val_cap) {
+    return (size_t)val_cap * 4 + (size_t)((width + 4) / 4) * 4 + (size_t)(width + 2) * 2;
+}
+
+// the few-rows kernel takes the call when it can; *taken says whether it did
+int run_few_payload(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out, uint64_t ld_out,
+                    hipStream_t stream, bool* taken) {
+    *taken = false;
+    if (a->n_rows > kFewRows || b->max_row_len > 64 || a->max_row_len >= 8192) return SDRB_OK;
+    const uint32_t width = (uint32_t)b->width;
+    const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
+    const uint32_t val_cap = (uint32_t)a->n_rows * (longest ? longest : 1u);   // < 65536: col[] is 16 bit
+    const size_t lds = few_lds_bytes(width, val_cap);
+    if (lds > 64 * 1024 - 256) return SDRB_OK;
+    *taken = true;
+    const int math = pick_math(a, b, op, swap);
+    const uint32_t quads = (b->max_row_len + 3) / 4;
+    const uint64_t pieces = ((uint64_t)b->n_rows + kFewBlock - 1) / kFewBlock;
+    const uint32_t per_cu = lds <= 8 * 1024 ? 8u : lds <= 16 * 1024 ? 6u : lds <= 32 * 1024 ? 4u : 2u;
+    const uint32_t grid = (uint32_t)(pieces < 256ull * per_cu ? pieces : 256ull * per_cu);
+#define SDRB_FEWP_LAUNCH_N(M, N)                                                                                     \
+    hipLaunchKernelGGL((k_size_few_payload<M, N>), dim3(grid), dim3(kFewBlock), lds, stream, a->d_offsets, a->d_ids, \
+                       a->d_data, (uint32_t)a->n_rows, b->d_offsets, b->d_ids, b->d_data, (uint64_t)b->n_rows, width, \
+                       op, swap ? 1u : 0u, val_cap, out, ld_out)
+#define SDRB_FEWP_LAUNCH(M)                              \
+    do {                                                 \
+        if (quads <= 4) SDRB_FEWP_LAUNCH_N(M, 4);        \
+        else if (quads <= 10) SDRB_FEWP_LAUNCH_N(M, 10); \
+        else SDRB_FEWP_LAUNCH_N(M, 16);                  \
+    } while (0)
+    switch (math) {
+    case kKeepAll: SDRB_FEWP_LAUNCH(kKeepAll); break;
+    case kDropAll: SDRB_FEWP_LAUNCH(kDropAll); break;
+    case kSelfA: SDRB_FEWP_LAUNCH(kSelfA); break;
+    case kSelfB: SDRB_FEWP_LAUNCH(kSelfB); break;
+    case kMul: SDRB_FEWP_LAUNCH(kMul); break;
+    case kAbsDiff: SDRB_FEWP_LAUNCH(kAbsDiff); break;
+    case kRmulA: SDRB_FEWP_LAUNCH(kRmulA); break;
+    default: SDRB_FEWP_LAUNCH(kRmulB); break;
+    }
+#undef SDRB_FEWP_LAUNCH
+#undef SDRB_FEWP_LAUNCH_N
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+}  // namespace
+
 int launch_size_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
                            uint64_t ld_out, hipStream_t stream) {
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    bool taken = false;
+    const int rc = run_few_payload(a, b, op, swap, out, ld_out, stream, &taken);
+    if (rc != SDRB_OK || taken) return rc;
     return run_mask_table(a, b, op, swap, false, out, ld_out, nullptr, nullptr, nullptr, stream);
 }
 

@@ -493,6 +493,23 @@ def test_mask_table_kernel_many_tiles_and_groups(name, width, max_len):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("nq,width,len_a,len_b", [(1, 2048, 40, 40), (8, 2048, 40, 40), (3, 4099, 300, 64), (5, 33, 33, 20),
+                                                  (8, 17000, 90, 7), (2, 1, 1, 1)])
+def test_few_rows_of_a_size_kernels_vs_oracle(name, nq, width, len_a, len_b):
+    """One query (or up to eight) against a database: the one-launch kernels with a byte per row of A in
+    the table word; every op, payload pairing and orientation, ragged rows, a partial last block."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(7 * nq + width + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, nq, width, len_a, tu))
+    a = Batch(*util.ragged_rows(rng, 777, width, len_b, au))
+    dt, da = dev(t, width), dev(a, width)
+    for op in range(4):
+        assert np.array_equal(gpu_sizes(op, dt, da), oracle.port().size_op(op, t, a)), op
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), op
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
 def test_batches_with_64_bit_ids_vs_reference(golden, name):
     """Rows with `long` ids (SDRElem<long, ...>, src/fuzz.cpp:413-423), far outside the 32-bit range:
     sizes and elements (int64 ids, payload bits) against what the reference itself returned."""
