@@ -198,12 +198,38 @@ def main() -> None:
                          "kernel_ms": kernel_ms, "algorithmic_bytes": algorithmic_bytes(nq, nd)},
             "parity_checked": verified,
         }
+        if world == 1 and args.op == "ands" and nq > 1:
+            n0 = int(q_off[1])
+            line["one_query"] = one_query_regime(engine.pack_host(q_off[:2], q_ids[:n0], None, WIDTH), db.shard, nd, dev)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(64, 100_000, threads)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def one_query_regime(q1, shard, nd: int, dev) -> dict:
+    """The other regime of the same op, reported beside the metric (never part of `value`): ONE query
+    against the resident rows, where reading the database, not writing counts, is the bound
+    (4*ACTIVE + 4 bytes of row, 4 bytes of count per pair-op)."""
+    import torch
+    out1 = torch.empty((1, nd), dtype=torch.int32, device=dev)
+    for _ in range(3):
+        q1.ands(shard, out=out1)
+    torch.cuda.synchronize()
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        q1.ands(shard, out=out1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = algorithmic_bytes(1, nd)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"workload": f"ands: 1 query x {nd} rows", "value": nd / (ms * 1e-3), "unit": "pair-ops/s",
+            "ms": ms, "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
 
 
 def _gather_rows(off, ids, rows):
