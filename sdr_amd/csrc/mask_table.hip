@@ -356,17 +356,21 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
 // LDS holds one BYTE per id (bit q: row q of A contains it), the column starts and the
 // column-compressed payloads of A as in the flat loop above; a lane's match and kept counts of
 // the eight pairs are bytes of two 32-bit registers each.  One launch, B read once, no atomics.
+// FILL: ande -- a lane walks its row in id order, so it writes the kept matches of each of its pairs
+// in order, starting at the pair's output offset (held in LDS, one column per lane).
 constexpr int kFewRows = 8;
 constexpr int kFewBlock = 256;
-template <int MATH, int NQ>
+template <int MATH, int NQ, bool FILL>
 __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val,
     uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
     const float* __restrict__ b_data, uint64_t nb, uint32_t width, int op, uint32_t swap, uint32_t val_cap,
-    uint32_t* __restrict__ out, uint64_t ld_out) {
+    uint32_t* __restrict__ out, uint64_t ld_out, const uint32_t* __restrict__ out_off,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_data) {
     constexpr bool NEED_A = MATH == kSelfA || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t pair_base[FILL ? kFewRows * kFewBlock : 1];   // [q][lane of the block]
     // LDS: vals[val_cap] | bits[(width + 4) / 4] (one byte per id, entry [width] stays zero) | col[width + 1]
     extern __shared__ __attribute__((aligned(16))) unsigned char few_raw[];
     float* vals = reinterpret_cast<float*>(few_raw);
@@ -443,6 +447,9 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
             ids[k4] = __builtin_amdgcn_raw_buffer_load_b128(ids_rsrc, (int)(rel + 16u * k4), 0, 0);
             if constexpr (NEED_B) vbs[k4] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, (int)(rel + 16u * k4), 0, 0);
         }
+        if constexpr (FILL) {
+            for (uint32_t q = 0; q < na; ++q) pair_base[q * kFewBlock + tid] = j < nb ? out_off[(uint64_t)q * nb + j] : 0u;
+        }
         uint32_t m_lo = 0, m_hi = 0, k_lo = 0, k_hi = 0;   // bytes: matches / kept matches of pairs 0..3, 4..7
 #pragma unroll
         for (int k4 = 0; k4 < NQ; ++k4) {
@@ -463,6 +470,13 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
                         float d;
                         const uint32_t kept = match_kept_by<MATH>(va, vb, d) ? 1u : 0u;
                         const uint32_t sh = 8 * (q & 3);
+                        if constexpr (FILL) {
+                            if (kept) {
+                                const uint32_t slot = pair_base[q * kFewBlock + tid] + (((q < 4 ? k_lo : k_hi) >> sh) & 0xffu);
+                                out_ids[slot] = (int32_t)id;
+                                if constexpr (MATH != kKeepAll) out_data[slot] = d;
+                            }
+                        }
                         if (q < 4) {
                             m_lo += 1u << sh;
                             k_lo += kept << sh;
@@ -477,6 +491,7 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
         uint32_t* dst = out + j;
 #pragma unroll
         for (int q = 0; q < kFewRows; ++q) {
+            if constexpr (FILL) break;
             const uint32_t mq = ((q < 4 ? m_lo : m_hi) >> (8 * (q & 3))) & 0xffu;
             const uint32_t kq = ((q < 4 ? k_lo : k_hi) >> (8 * (q & 3))) & 0xffu;
             const uint32_t l_this = swap ? lb : la[q], l_arg = swap ? la[q] : lb;
@@ -642,25 +657,32 @@ size_t few_lds_bytes(uint32_t width, uint32_t val_cap) {
 }
 
 // the few-rows kernel takes the call when it can; *taken says whether it did
-int run_few_payload(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out, uint64_t ld_out,
-                    hipStream_t stream, bool* taken) {
+int run_few_payload(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, bool fill, uint32_t* out,
+                    uint64_t ld_out, const uint32_t* out_off, int32_t* out_ids, float* out_data, hipStream_t stream,
+                    bool* taken) {
     *taken = false;
     if (a->n_rows > kFewRows || b->max_row_len > 64 || a->max_row_len >= 8192) return SDRB_OK;
     const uint32_t width = (uint32_t)b->width;
     const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
     const uint32_t val_cap = (uint32_t)a->n_rows * (longest ? longest : 1u);   // < 65536: col[] is 16 bit
     const size_t lds = few_lds_bytes(width, val_cap);
-    if (lds > 64 * 1024 - 256) return SDRB_OK;
+    if (lds + (fill ? kFewRows * kFewBlock * 4 : 0) > 64 * 1024 - 256) return SDRB_OK;
     *taken = true;
     const int math = pick_math(a, b, op, swap);
     const uint32_t quads = (b->max_row_len + 3) / 4;
     const uint64_t pieces = ((uint64_t)b->n_rows + kFewBlock - 1) / kFewBlock;
     const uint32_t per_cu = lds <= 8 * 1024 ? 8u : lds <= 16 * 1024 ? 6u : lds <= 32 * 1024 ? 4u : 2u;
     const uint32_t grid = (uint32_t)(pieces < 256ull * per_cu ? pieces : 256ull * per_cu);
-#define SDRB_FEWP_LAUNCH_N(M, N)                                                                                     \
-    hipLaunchKernelGGL((k_size_few_payload<M, N>), dim3(grid), dim3(kFewBlock), lds, stream, a->d_offsets, a->d_ids, \
-                       a->d_data, (uint32_t)a->n_rows, b->d_offsets, b->d_ids, b->d_data, (uint64_t)b->n_rows, width, \
-                       op, swap ? 1u : 0u, val_cap, out, ld_out)
+#define SDRB_FEWP_LAUNCH_NF(M, N, F)                                                                                 \
+    hipLaunchKernelGGL((k_size_few_payload<M, N, F>), dim3(grid), dim3(kFewBlock), lds, stream, a->d_offsets,        \
+                       a->d_ids, a->d_data, (uint32_t)a->n_rows, b->d_offsets, b->d_ids, b->d_data,                  \
+                       (uint64_t)b->n_rows, width, op, swap ? 1u : 0u, val_cap, out, ld_out, out_off, out_ids,       \
+                       out_data)
+#define SDRB_FEWP_LAUNCH_N(M, N)                     \
+    do {                                             \
+        if (fill) SDRB_FEWP_LAUNCH_NF(M, N, true);   \
+        else SDRB_FEWP_LAUNCH_NF(M, N, false);       \
+    } while (0)
 #define SDRB_FEWP_LAUNCH(M)                              \
     do {                                                 \
         if (quads <= 4) SDRB_FEWP_LAUNCH_N(M, 4);        \
@@ -679,6 +701,7 @@ int run_few_payload(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
     }
 #undef SDRB_FEWP_LAUNCH
 #undef SDRB_FEWP_LAUNCH_N
+#undef SDRB_FEWP_LAUNCH_NF
     SDRB_HIP(hipGetLastError());
     return SDRB_OK;
 }
@@ -689,7 +712,7 @@ int launch_size_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, boo
                            uint64_t ld_out, hipStream_t stream) {
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
     bool taken = false;
-    const int rc = run_few_payload(a, b, op, swap, out, ld_out, stream, &taken);
+    const int rc = run_few_payload(a, b, op, swap, false, out, ld_out, nullptr, nullptr, nullptr, stream, &taken);
     if (rc != SDRB_OK || taken) return rc;
     return run_mask_table(a, b, op, swap, false, out, ld_out, nullptr, nullptr, nullptr, stream);
 }
@@ -698,6 +721,9 @@ int launch_size_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, boo
 int launch_elem_mask_table(const sdrb_batch* a, const sdrb_batch* b, bool swap, const uint32_t* out_offsets,
                            int32_t* out_ids, float* out_data, hipStream_t stream) {
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    bool taken = false;
+    const int rc = run_few_payload(a, b, SDRB_OP_AND, swap, true, nullptr, 0, out_offsets, out_ids, out_data, stream, &taken);
+    if (rc != SDRB_OK || taken) return rc;
     return run_mask_table(a, b, SDRB_OP_AND, swap, true, nullptr, 0, out_offsets, out_ids, out_data, stream);
 }
 
