@@ -195,15 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                     if constexpr (NEED_B) vb = b_data[beg + e];
                 }
             };
-            uint32_t id, nxt_id = width;
-            float vb, nxt_vb = 0.0f;
-            fetch(0, id, vb);
-            // the first elements are waited for here, not inside the loop, where the wait would also
-            // cover the elements requested for the next turn
-            asm volatile("" : "+v"(id), "+v"(vb));
-#pragma unroll 1
-            for (uint32_t s0 = 0; s0 < LPE * n; s0 += 64) {
-                if (s0 + 64 < LPE * n) fetch(s0 + 64, nxt_id, nxt_vb);
+            auto visit_pass = [&](uint32_t s0, uint32_t id, float vb) {
                 const uint32_t e = (s0 + lane) / LPE;
                 uint32_t jl = r0;
 #pragma unroll
@@ -234,8 +226,33 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                         if constexpr (MATH != kKeepAll) out_data[slot] = d;
                     }
                 }
-                id = nxt_id;
-                vb = nxt_vb;
+            };
+            // The fill stores inside the bit loop, and on this hardware a wait for a load also waits for
+            // every store issued before it: when the wave's elements fit NP registers per lane they are
+            // all fetched before the first store, so that nothing waits for a store until the group ends.
+            constexpr int NP = FILL ? (TILE == 32 ? 24 : 8) : 0;
+            if (FILL && LPE * n <= (uint32_t)NP * 64u) {
+                uint32_t held_id[NP ? NP : 1];
+                float held_vb[NP ? NP : 1];
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) fetch((uint32_t)pass * 64u, held_id[pass], held_vb[pass]);
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass)
+                    if ((uint32_t)pass * 64u < LPE * n) visit_pass((uint32_t)pass * 64u, held_id[pass], held_vb[pass]);
+            } else {
+                uint32_t id, nxt_id = width;
+                float vb, nxt_vb = 0.0f;
+                fetch(0, id, vb);
+                // the first elements are waited for here, not inside the loop, where the wait would also
+                // cover the elements requested for the next turn
+                asm volatile("" : "+v"(id), "+v"(vb));
+#pragma unroll 1
+                for (uint32_t s0 = 0; s0 < LPE * n; s0 += 64) {
+                    if (s0 + 64 < LPE * n) fetch(s0 + 64, nxt_id, nxt_vb);
+                    visit_pass(s0, id, vb);
+                    id = nxt_id;
+                    vb = nxt_vb;
+                }
             }
         } else {
             // Rows of up to 64*NIT elements travel HBM -> registers whole (bounds-checked buffer loads, all
