@@ -1,5 +1,6 @@
 // Element operations ande/ore/xore/rme over every pair of two batches:
-// count (a size op) -> exclusive scan -> fill.  This file holds the scan and the fill.
+// count (a size op) -> exclusive scan -> fill.  This file holds the scan (rocPRIM's single-pass
+// device scan, in place) and the general fill.
 //
 // Fill: one lane owns pair (i, j) and walks row i of A against row j of B with the
 // three-way merge of the reference's union visitor orv (SDR.hpp:1099-1150), emitting
@@ -12,6 +13,8 @@
 // becomes UnitData 1.0 (UnitData.hpp:13-14), a UnitData argument loses its payload in an
 // EmptyData result (EmptyData.hpp:25-27).
 #include "sdrb_device.h"
+#include <rocprim/device/device_scan.hpp>
+
 #include "sdrb_internal.h"
 
 namespace sdrb {
@@ -19,68 +22,6 @@ namespace sdrb {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kScanPerThread = 8;
-constexpr int kScanPerBlock = kBlock * kScanPerThread;
-
-// In-place exclusive scan of one 2048-element chunk per block; block totals to `sums`.
-__global__ __launch_bounds__(kBlock) void k_scan_chunks(uint32_t* __restrict__ data, uint64_t n,
-                                                        uint32_t* __restrict__ sums) {
-    __shared__ uint32_t wave_tot[kBlock / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kScanPerBlock + (uint64_t)threadIdx.x * kScanPerThread;
-    uint32_t v[kScanPerThread];
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        const uint64_t idx = base + k;
-        const uint32_t x = idx < n ? data[idx] : 0u;
-        v[k] = run;
-        run += x;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = run;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w)
-        if (w < wave) wave_base += wave_tot[w];
-    const uint32_t thread_base = wave_base + incl - run;
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        const uint64_t idx = base + k;
-        if (idx < n) data[idx] = v[k] + thread_base;
-    }
-    if (threadIdx.x == kBlock - 1) sums[blockIdx.x] = thread_base + run;
-}
-
-__global__ __launch_bounds__(kBlock) void k_add_chunk_base(uint32_t* __restrict__ data, uint64_t n,
-                                                           const uint32_t* __restrict__ sums) {
-    const uint32_t add = sums[blockIdx.x];
-    const uint64_t base = (uint64_t)blockIdx.x * kScanPerBlock + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        const uint64_t idx = base + (uint64_t)k * kBlock;
-        if (idx < n) data[idx] += add;
-    }
-}
-
-int scan_level(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t stream) {
-    const uint64_t nchunks = (n + kScanPerBlock - 1) / kScanPerBlock;
-    hipLaunchKernelGGL(k_scan_chunks, dim3((uint32_t)nchunks), dim3(kBlock), 0, stream, data, n, sums);
-    SDRB_HIP(hipGetLastError());
-    if (nchunks > 1) {
-        int rc = scan_level(sums, nchunks, sums + nchunks, stream);
-        if (rc != SDRB_OK) return rc;
-        hipLaunchKernelGGL(k_add_chunk_base, dim3((uint32_t)nchunks), dim3(kBlock), 0, stream, data, n, sums);
-        SDRB_HIP(hipGetLastError());
-    }
-    return SDRB_OK;
-}
 
 // VISIT (ids only, ande / ore): instead of elements, the positions a visitor of andv / orv would be called
 // with -- out_ids (as uint32) gets the position in `this`, out_data (as uint32) the position in `arg`,
@@ -246,16 +187,13 @@ void launch_swap(const FillArgs& g, bool swap) {
 
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream) {
     if (n == 0) return SDRB_OK;
-    // block sums of every recursion level, laid out back to back
-    uint64_t total_sums = 0;
-    for (uint64_t m = n; m > 1;) {
-        m = (m + kScanPerBlock - 1) / kScanPerBlock;
-        total_sums += m;
-        if (m == 1) break;
-    }
-    uint32_t* sums = static_cast<uint32_t*>(workspace(device, 1, (total_sums + 1) * sizeof(uint32_t)));
-    if (!sums) return SDRB_ERR_HIP;
-    return scan_level(data, n, sums, stream);
+    // single-pass scan (decoupled look-back, rocPRIM): the array is read once and written once, in place
+    size_t temp_bytes = 0;
+    SDRB_HIP(rocprim::exclusive_scan(nullptr, temp_bytes, data, data, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    void* temp = workspace(device, 1, temp_bytes ? temp_bytes : 1);
+    if (!temp) return SDRB_ERR_HIP;
+    SDRB_HIP(rocprim::exclusive_scan(temp, temp_bytes, data, data, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    return SDRB_OK;
 }
 
 namespace {
