@@ -158,25 +158,56 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
     }
     __syncthreads();
 
+    // A row of B and the output offsets of its pairs are requested one row ahead, into registers (rows of
+    // up to 64 * kHeld elements; longer rows are fetched when their turn comes): a wait for a load
+    // also waits for every store issued before it, so loads must not sit between a row's stores.
+    constexpr int kHeld = 8;
+    uint32_t held_id[kHeld];
+    float held_val[kHeld];
+    uint32_t held_beg = 0, held_len = 0;
+    int held_base = 0;
+    auto request_row = [&](uint64_t j) {
+        held_beg = b_off[j];
+        held_len = b_off[j + 1] - held_beg;   // <= cap_b (host)
+        held_base = lane < ni ? (int)out_off[(uint64_t)(i_begin + lane) * nb + j] : 0;
+#pragma unroll
+        for (int c = 0; c < kHeld; ++c) {
+            const uint32_t k = (uint32_t)c * 64u + lane;
+            held_id[c] = 0;
+            held_val[c] = 0.0f;
+            if (k < held_len) {
+                held_id[c] = (uint32_t)b_ids[held_beg + k];
+                if constexpr (B_UNIT) held_val[c] = b_data[held_beg + k];
+            }
+        }
+    };
+    if (j_begin < j_end) request_row(j_begin);
     for (uint64_t j = j_begin; j < j_end; ++j) {
-        const uint32_t b_beg = b_off[j], lb = b_off[j + 1] - b_beg;   // lb <= cap_b (host)
-        const int base_reg = lane < ni ? (int)out_off[(uint64_t)(i_begin + lane) * nb + j] : 0;
+        const uint32_t b_beg = held_beg, lb = held_len;
+        const int base_reg = held_base;
         // row j of B: copy it into LDS and build its table (zero, OR the ids in, prefix the popcounts)
         for (uint32_t w = lane; w < nw; w += 64) lds_store(reinterpret_cast<u64*>(btab + w), (u64)0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        uint32_t b_x0 = 0;
-        float b_v0 = 0.0f;
-        for (uint32_t k = lane; k < lb; k += 64) {
+        const uint32_t b_x0 = held_id[0];
+        const float b_v0 = held_val[0];
+#pragma unroll
+        for (int c = 0; c < kHeld; ++c) {
+            const uint32_t k = (uint32_t)c * 64u + lane;
+            if (k < lb) {
+                lds_store(&b_ids_l[k], held_id[c]);
+                lds_store(&b_val_l[k], held_val[c]);
+                __hip_atomic_fetch_or(&btab[held_id[c] >> 5].bits, 1u << (held_id[c] & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        for (uint32_t k = (uint32_t)kHeld * 64u + lane; k < lb; k += 64) {
             const uint32_t id = (uint32_t)b_ids[b_beg + k];
             const float val = B_UNIT ? b_data[b_beg + k] : 0.0f;
-            if (k < 64) {
-                b_x0 = id;
-                b_v0 = val;
-            }
             lds_store(&b_ids_l[k], id);
             lds_store(&b_val_l[k], val);
             __hip_atomic_fetch_or(&btab[id >> 5].bits, 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+        if (j + 1 < j_end) request_row(j + 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         uint32_t run = 0;
         for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
