@@ -129,13 +129,15 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
     constexpr bool UNION = OP == SDRB_OP_OR || OP == SDRB_OP_XOR;
     // matches of a xore can be dropped one by one only when `this` carries payloads
     constexpr bool DROP_BY_VALUE = OP == SDRB_OP_XOR && THIS_UNIT;
-    // LDS: tables of the waves' rows of B | tables of the block's rows of A | rows of A: ids, payloads |
-    //      the waves' rows of B: ids, payloads   (cap_a / cap_b elements per row)
+    // the tables of A are looked up by the walk over `arg` of a union, and as `arg` when A is `arg`
+    constexpr bool NEED_ATAB = UNION || SWAP;
+    // LDS: tables of the waves' rows of B | tables of the block's rows of A (if needed) | rows of A: ids,
+    //      payloads | the waves' rows of B: ids, payloads   (cap_a / cap_b elements per row)
     extern __shared__ RankEntry smem[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RankEntry* btab = smem + (size_t)wave * nw;
     RankEntry* atab_all = smem + (size_t)kWaves * nw;
-    uint32_t* a_ids_all = reinterpret_cast<uint32_t*>(atab_all + (size_t)qc * nw);
+    uint32_t* a_ids_all = reinterpret_cast<uint32_t*>(atab_all + (NEED_ATAB ? (size_t)qc * nw : (size_t)0));
     float* a_val_all = reinterpret_cast<float*>(a_ids_all + (size_t)qc * cap_a);
     uint32_t* b_ids_l = reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * cap_a) + (size_t)wave * cap_b;
     float* b_val_l = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * cap_a) +
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
     // row offsets of the block's rows of A, one per lane (lanes 0..ni)
     const int a_off_reg = (int)a_off[i_begin + (lane <= ni ? lane : ni)];
 
-    for (uint32_t idx = threadIdx.x; idx < ni * nw; idx += kBlock) atab_all[idx] = a_tab[(size_t)i_begin * nw + idx];
+    if constexpr (NEED_ATAB)
+        for (uint32_t idx = threadIdx.x; idx < ni * nw; idx += kBlock) atab_all[idx] = a_tab[(size_t)i_begin * nw + idx];
     for (uint32_t ii = 0; ii < ni; ++ii) {
         const uint32_t beg = a_off[i_begin + ii], len = a_off[i_begin + ii + 1] - beg;   // len <= cap_a (host)
         for (uint32_t l = threadIdx.x; l < len; l += kBlock) {
@@ -872,13 +875,14 @@ size_t lds_bytes_short(uint32_t nw, uint32_t qc) {
            (size_t)kWaves * kShortRows * kShortCap * 8 + (size_t)kWaves * kShortRows * qc * 4;
 }
 
-size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b) {
-    return ((size_t)kWaves * nw + (size_t)qc * nw) * sizeof(RankEntry) + ((size_t)qc * cap_a + (size_t)kWaves * cap_b) * 8;
+size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b, bool a_tables) {
+    return ((size_t)kWaves * nw + (a_tables ? (size_t)qc * nw : (size_t)0)) * sizeof(RankEntry) +
+           ((size_t)qc * cap_a + (size_t)kWaves * cap_b) * 8;
 }
 
 // rows of A per block: up to kQueryChunk, fewer when tables and rows are large (a row of B's table is
 // rebuilt for every block that visits it, so more rows of A per block beat more blocks per compute unit)
-Shape shape_for(const sdrb_batch* a, const sdrb_batch* b) {
+Shape shape_for(const sdrb_batch* a, const sdrb_batch* b, bool a_tables = true) {
     Shape s;
     s.nw = (uint32_t)(((size_t)b->width + 31) / 32);
     s.cap_a = (a->max_row_len + 63) / 64 * 64;
@@ -905,8 +909,8 @@ Shape shape_for(const sdrb_batch* a, const sdrb_batch* b) {
         s.short_rows = false;
         s.qc = kQueryChunk;
     }
-    while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b) > kLdsWanted) s.qc >>= 1;
-    s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b);
+    while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables) > kLdsWanted) s.qc >>= 1;
+    s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables);
     s.ok = s.lds <= kLdsLimit;
     return s;
 }
@@ -925,7 +929,8 @@ bool elem_rank_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 
 int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
                      int32_t* out_ids, float* out_data, hipStream_t stream, bool visit) {
-    const Shape shape = shape_for(a, b);
+    // the long-row kernel stages the tables of A only where it looks them up (unions, or A as `arg`)
+    const Shape shape = shape_for(a, b, op == SDRB_OP_OR || op == SDRB_OP_XOR || swap);
     const uint32_t nw = shape.nw;
     RankEntry* a_tab = static_cast<RankEntry*>(workspace(b->device, 9, (size_t)a->n_rows * nw * sizeof(RankEntry)));
     if (!a_tab) return SDRB_ERR_HIP;
