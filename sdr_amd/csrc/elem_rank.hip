@@ -131,12 +131,14 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
     constexpr bool DROP_BY_VALUE = OP == SDRB_OP_XOR && THIS_UNIT;
     // the tables of A are looked up by the walk over `arg` of a union, and as `arg` when A is `arg`
     constexpr bool NEED_ATAB = UNION || SWAP;
+    // ... and those of B likewise: by a union's second walk, and as `arg` when B is `arg`
+    constexpr bool NEED_BTAB = UNION || !SWAP;
     // LDS: tables of the waves' rows of B | tables of the block's rows of A (if needed) | rows of A: ids,
     //      payloads | the waves' rows of B: ids, payloads   (cap_a / cap_b elements per row)
     extern __shared__ RankEntry smem[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RankEntry* btab = smem + (size_t)wave * nw;
-    RankEntry* atab_all = smem + (size_t)kWaves * nw;
+    RankEntry* atab_all = smem + (NEED_BTAB ? (size_t)kWaves * nw : (size_t)0);
     uint32_t* a_ids_all = reinterpret_cast<uint32_t*>(atab_all + (NEED_ATAB ? (size_t)qc * nw : (size_t)0));
     float* a_val_all = reinterpret_cast<float*>(a_ids_all + (size_t)qc * cap_a);
     uint32_t* b_ids_l = reinterpret_cast<uint32_t*>(a_val_all + (size_t)qc * cap_a) + (size_t)wave * cap_b;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
         const uint32_t b_beg = held_beg, lb = held_len;
         const int base_reg = held_base;
         // row j of B: copy it into LDS and build its table (zero, OR the ids in, prefix the popcounts)
-        for (uint32_t w = lane; w < nw; w += 64) lds_store(reinterpret_cast<u64*>(btab + w), (u64)0);
+        if constexpr (NEED_BTAB)
+            for (uint32_t w = lane; w < nw; w += 64) lds_store(reinterpret_cast<u64*>(btab + w), (u64)0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const uint32_t b_x0 = held_id[0];
         const float b_v0 = held_val[0];
@@ -199,8 +202,9 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
             if (k < lb) {
                 lds_store(&b_ids_l[k], held_id[c]);
                 lds_store(&b_val_l[k], held_val[c]);
-                __hip_atomic_fetch_or(&btab[held_id[c] >> 5].bits, 1u << (held_id[c] & 31), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if constexpr (NEED_BTAB)
+                    __hip_atomic_fetch_or(&btab[held_id[c] >> 5].bits, 1u << (held_id[c] & 31), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         for (uint32_t k = (uint32_t)kHeld * 64u + lane; k < lb; k += 64) {
@@ -208,12 +212,13 @@ __global__ __launch_bounds__(kBlock) void k_elem_rank(
             const float val = B_UNIT ? b_data[b_beg + k] : 0.0f;
             lds_store(&b_ids_l[k], id);
             lds_store(&b_val_l[k], val);
-            __hip_atomic_fetch_or(&btab[id >> 5].bits, 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if constexpr (NEED_BTAB)
+                __hip_atomic_fetch_or(&btab[id >> 5].bits, 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         if (j + 1 < j_end) request_row(j + 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         uint32_t run = 0;
-        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+        for (uint32_t w0 = 0; NEED_BTAB && w0 < nw; w0 += 64) {
             const uint32_t w = w0 + lane;
             const uint32_t c = w < nw ? (uint32_t)__builtin_popcount(lds_load(&btab[w].bits)) : 0u;
             const uint32_t incl = wave_inclusive_scan(c);
@@ -875,14 +880,14 @@ size_t lds_bytes_short(uint32_t nw, uint32_t qc) {
            (size_t)kWaves * kShortRows * kShortCap * 8 + (size_t)kWaves * kShortRows * qc * 4;
 }
 
-size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b, bool a_tables) {
-    return ((size_t)kWaves * nw + (a_tables ? (size_t)qc * nw : (size_t)0)) * sizeof(RankEntry) +
+size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b, bool a_tables, bool b_tables) {
+    return ((b_tables ? (size_t)kWaves * nw : (size_t)0) + (a_tables ? (size_t)qc * nw : (size_t)0)) * sizeof(RankEntry) +
            ((size_t)qc * cap_a + (size_t)kWaves * cap_b) * 8;
 }
 
 // rows of A per block: up to kQueryChunk, fewer when tables and rows are large (a row of B's table is
 // rebuilt for every block that visits it, so more rows of A per block beat more blocks per compute unit)
-Shape shape_for(const sdrb_batch* a, const sdrb_batch* b, bool a_tables = true) {
+Shape shape_for(const sdrb_batch* a, const sdrb_batch* b, bool a_tables = true, bool b_tables = true) {
     Shape s;
     s.nw = (uint32_t)(((size_t)b->width + 31) / 32);
     s.cap_a = (a->max_row_len + 63) / 64 * 64;
@@ -909,8 +914,8 @@ Shape shape_for(const sdrb_batch* a, const sdrb_batch* b, bool a_tables = true) 
         s.short_rows = false;
         s.qc = kQueryChunk;
     }
-    while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables) > kLdsWanted) s.qc >>= 1;
-    s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables);
+    while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables) > kLdsWanted) s.qc >>= 1;
+    s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables);
     s.ok = s.lds <= kLdsLimit;
     return s;
 }
@@ -929,8 +934,10 @@ bool elem_rank_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 
 int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
                      int32_t* out_ids, float* out_data, hipStream_t stream, bool visit) {
-    // the long-row kernel stages the tables of A only where it looks them up (unions, or A as `arg`)
-    const Shape shape = shape_for(a, b, op == SDRB_OP_OR || op == SDRB_OP_XOR || swap);
+    // the long-row kernel stages / builds a batch's tables only where it looks them up (unions, or the
+    // batch as `arg`)
+    const bool is_union = op == SDRB_OP_OR || op == SDRB_OP_XOR;
+    const Shape shape = shape_for(a, b, is_union || swap, is_union || !swap);
     const uint32_t nw = shape.nw;
     RankEntry* a_tab = static_cast<RankEntry*>(workspace(b->device, 9, (size_t)a->n_rows * nw * sizeof(RankEntry)));
     if (!a_tab) return SDRB_ERR_HIP;
