@@ -818,6 +818,9 @@ void launch(const Args& g) {
                                g.rows_per_wave);
         return;
     }
+    if (g.lds > 64 * 1024)   // beyond the default limit of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
                        g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets, g.b->d_ids, g.b->d_data,
                        (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc, g.cap_a, g.cap_b, g.rows_per_wave);
@@ -856,8 +859,9 @@ void launch_swap(const Args& g, bool swap) {
 
 constexpr int32_t kMaxWidth = 32768;           // 8 KiB of table per row
 constexpr size_t kMaxTableBytes = 512u << 20;  // tables of A in global memory
-constexpr size_t kLdsWanted = 64 * 1024;       // rows of A per block are halved until a block fits this
-constexpr size_t kLdsLimit = 64 * 1024;        // what a block may use at most
+constexpr size_t kLdsWanted = 80 * 1024;       // rows of A per block are halved until a block fits this (two blocks per CU)
+constexpr size_t kLdsLimit = 80 * 1024;        // what a block may use at most
+constexpr size_t kLdsThird = 53 * 1024;        // three blocks per compute unit
 constexpr size_t kLdsShortWanted = 40 * 1024;  // short-row kernel: four blocks per compute unit
 constexpr size_t kLdsRunsLimit = 52 * 1024;    // coalesced-run kernel: three blocks per compute unit
 
@@ -890,10 +894,10 @@ size_t lds_bytes(uint32_t nw, uint32_t qc, uint32_t cap_a, uint32_t cap_b, bool 
 Shape shape_for(const sdrb_batch* a, const sdrb_batch* b, bool a_tables = true, bool b_tables = true) {
     Shape s;
     s.nw = (uint32_t)(((size_t)b->width + 31) / 32);
-    s.cap_a = (a->max_row_len + 63) / 64 * 64;
-    s.cap_b = (b->max_row_len + 63) / 64 * 64;
-    if (s.cap_a == 0) s.cap_a = 64;
-    if (s.cap_b == 0) s.cap_b = 64;
+    s.cap_a = (a->max_row_len + 7) / 8 * 8;
+    s.cap_b = (b->max_row_len + 7) / 8 * 8;
+    if (s.cap_a == 0) s.cap_a = 8;
+    if (s.cap_b == 0) s.cap_b = 8;
     s.qc = kQueryChunk;
     // short rows on both sides and enough rows of A to fill the four lane groups: the short-row kernel
     s.short_rows = a->max_row_len <= (uint32_t)kShortCap && b->max_row_len <= (uint32_t)kShortCap && a->n_rows >= 4;
@@ -914,7 +918,12 @@ Shape shape_for(const sdrb_batch* a, const sdrb_batch* b, bool a_tables = true, 
         s.short_rows = false;
         s.qc = kQueryChunk;
     }
-    while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables) > kLdsWanted) s.qc >>= 1;
+    // three blocks per compute unit if eight rows of A still fit a block then, else two blocks
+    while (s.qc > 8 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables) > kLdsThird) s.qc >>= 1;
+    if (lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables) > kLdsThird) {
+        s.qc = kQueryChunk;
+        while (s.qc > 1 && lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables) > kLdsWanted) s.qc >>= 1;
+    }
     s.lds = lds_bytes(s.nw, s.qc, s.cap_a, s.cap_b, a_tables, b_tables);
     s.ok = s.lds <= kLdsLimit;
     return s;
