@@ -134,6 +134,124 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? 2 : 1) void k_inner_table(
 }
 
 // ---------------------------------------------------------------- general per-pair merge
+// ---------------------------------------------------------------- few rows of A (matrix x vector)
+// Up to eight rows of A against rows of B of at most 64 ids (row_major_mul_vec is the one-row case):
+// a lane owns a row of B, fetched with 16-byte loads that are all issued up front, and walks it in
+// id order, so the matches of each of its pairs are added in ascending id order by construction.
+// LDS holds one byte per id (bit q: row q of A contains it), and the values of A column-compressed:
+// col[w] says where the values of id w start, in ascending row order.  One launch, B read once.
+constexpr int kFewRows = 8;
+template <int NQ, bool B_HAS_VALUES>
+__global__ __launch_bounds__(kBlock) void k_inner_few(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val,
+    uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
+    const float* __restrict__ b_val, uint64_t nb, uint32_t width, uint32_t val_cap,
+    float* __restrict__ out, uint64_t ld_out) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // LDS: vals[val_cap] | bits[(width + 4) / 4 words] (entry [width] stays zero) | col[width + 1]
+    extern __shared__ __attribute__((aligned(16))) unsigned char few_raw[];
+    float* vals = reinterpret_cast<float*>(few_raw);
+    uint32_t* bits32 = reinterpret_cast<uint32_t*>(vals + val_cap);
+    const unsigned char* bits = reinterpret_cast<const unsigned char*>(bits32);
+    const uint32_t words = (width + 4) / 4;
+    uint16_t* col = reinterpret_cast<uint16_t*>(bits32 + words);
+    __shared__ uint32_t wave_tot[kBlock / 64];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t w = tid; w < words; w += kBlock) bits32[w] = 0;
+    __syncthreads();
+    for (uint32_t q = 0; q < na; ++q) {
+        const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+        for (uint32_t k = tid; k < len; k += kBlock) {
+            const uint32_t id = (uint32_t)a_ids[beg + k];
+            if (id < width) atomicOr(&bits32[id >> 2], (1u << q) << (8 * (id & 3)));   // ids outside B's width never match
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t per = (width + kBlock) / kBlock;
+        const uint32_t w0 = tid * per < width + 1 ? tid * per : width + 1;
+        const uint32_t w1 = w0 + per < width + 1 ? w0 + per : width + 1;
+        uint32_t mine = 0;
+        for (uint32_t w = w0; w < w1; ++w) mine += (uint32_t)__builtin_popcount(bits[w]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) run += wave_tot[w];
+        for (uint32_t w = w0; w < w1; ++w) {
+            col[w] = (uint16_t)run;
+            run += (uint32_t)__builtin_popcount(bits[w]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < na; ++q) {
+        const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+        for (uint32_t k = tid; k < len; k += kBlock) {
+            const uint32_t id = (uint32_t)a_ids[beg + k];
+            if (id < width) vals[col[id] + (uint32_t)__builtin_popcount(bits[id] & ((1u << q) - 1u))] = a_val[beg + k];
+        }
+    }
+    __syncthreads();
+
+    const uint64_t pieces = (nb + kBlock - 1) / kBlock;
+    for (uint64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
+        const uint64_t j0 = piece * kBlock, j = j0 + tid;
+        uint32_t beg = 0, lb = 0;
+        if (j < nb) {
+            beg = b_off[j];
+            lb = b_off[j + 1] - beg;
+        }
+        const uint32_t blk_beg = b_off[j0];                                   // uniform
+        const uint64_t blk_last = j0 + kBlock < nb ? j0 + kBlock : nb;
+        const uint32_t blk_bytes = (b_off[blk_last] - blk_beg) * 4u;          // uniform
+        __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int32_t*>(b_ids) + blk_beg, 0, (int)blk_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(b_val) + (B_HAS_VALUES ? blk_beg : 0u), 0, B_HAS_VALUES ? (int)blk_bytes : 0, 0x00020000);
+        const uint32_t rel = (beg - blk_beg) * 4u;
+        u32x4 ids[NQ], vbs[B_HAS_VALUES ? NQ : 1];
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; ++k4) {
+            ids[k4] = __builtin_amdgcn_raw_buffer_load_b128(ids_rsrc, (int)(rel + 16u * k4), 0, 0);
+            if constexpr (B_HAS_VALUES) vbs[k4] = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, (int)(rel + 16u * k4), 0, 0);
+        }
+        float acc[kFewRows];
+#pragma unroll
+        for (int q = 0; q < kFewRows; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; ++k4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t id = (uint32_t)(4 * k4 + c) < lb ? ids[k4][c] : width;
+                const uint32_t m = bits[id];
+                if (m != 0) {
+                    uint32_t at = col[id];
+#pragma unroll
+                    for (int q = 0; q < kFewRows; ++q) {
+                        if (m & (1u << q)) {
+                            const float va = vals[at++];
+                            const float term = B_HAS_VALUES ? va * __builtin_bit_cast(float, (uint32_t)vbs[k4][c]) : va;
+                            acc[q] = acc[q] + term;
+                        }
+                    }
+                }
+            }
+        }
+        float* dst = out + j;
+#pragma unroll
+        for (int q = 0; q < kFewRows; ++q) {
+            if ((uint32_t)q < na && j < nb) __builtin_nontemporal_store(acc[q], dst);
+            dst += ld_out;
+        }
+    }
+}
+
 template <bool B_HAS_VALUES>
 __global__ __launch_bounds__(kBlock) void k_inner_merge(const uint32_t* __restrict__ a_off,
                                                          const int32_t* __restrict__ a_ids,
@@ -200,6 +318,35 @@ bool table_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 }  // namespace
 
 int launch_inner(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t ld_out, hipStream_t stream) {
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    if (a->n_rows <= kFewRows && b->width > 0 && b->max_row_len <= 64 && a->max_row_len < 8192) {
+        const uint32_t width = (uint32_t)b->width;
+        const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
+        const uint32_t val_cap = (uint32_t)a->n_rows * (longest ? longest : 1u);   // < 65536: col[] is 16 bit
+        const size_t lds = (size_t)val_cap * 4 + (size_t)((width + 4) / 4) * 4 + (size_t)(width + 2) * 2;
+        if (lds <= 64 * 1024 - 256) {
+            const uint32_t quads = (b->max_row_len + 3) / 4;
+            const uint64_t pieces = ((uint64_t)b->n_rows + kBlock - 1) / kBlock;
+            const uint32_t per_cu = lds <= 8 * 1024 ? 8u : lds <= 16 * 1024 ? 6u : lds <= 32 * 1024 ? 4u : 2u;
+            const uint32_t grid = (uint32_t)(pieces < 256ull * per_cu ? pieces : 256ull * per_cu);
+#define SDRB_INNER_FEW_NV(N, V)                                                                                    \
+    hipLaunchKernelGGL((k_inner_few<N, V>), dim3(grid), dim3(kBlock), lds, stream, a->d_offsets, a->d_ids, a->d_data, \
+                       (uint32_t)a->n_rows, b->d_offsets, b->d_ids, b->d_data, (uint64_t)b->n_rows, width, val_cap,   \
+                       out, ld_out)
+#define SDRB_INNER_FEW(N)                         \
+    do {                                          \
+        if (b->d_data) SDRB_INNER_FEW_NV(N, true); \
+        else SDRB_INNER_FEW_NV(N, false);          \
+    } while (0)
+            if (quads <= 4) SDRB_INNER_FEW(4);
+            else if (quads <= 10) SDRB_INNER_FEW(10);
+            else SDRB_INNER_FEW(16);
+#undef SDRB_INNER_FEW
+#undef SDRB_INNER_FEW_NV
+            SDRB_HIP(hipGetLastError());
+            return SDRB_OK;
+        }
+    }
     if (!table_applicable(a, b)) {
         const dim3 grid((uint32_t)((b->n_rows + kBlock - 1) / kBlock), (uint32_t)a->n_rows);
         if (a->n_rows > 65535) {

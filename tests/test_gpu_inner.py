@@ -35,9 +35,11 @@ def test_inner_vs_golden(golden, tag, width):
 
 
 @pytest.mark.parametrize("width,max_len,nt,na", [(2048, 40, 37, 1000), (4096, 64, 5, 700), (300, 16, 130, 513),
-                                                 (2048, 40, 1, 3000)])
+                                                 (2048, 40, 1, 3000), (4099, 64, 8, 777), (33, 20, 3, 300),
+                                                 (17001, 7, 2, 515), (2048, 64, 9, 300)])
 def test_inner_table_kernel_vs_oracle(width, max_len, nt, na):
-    """Ragged rows, partial 4-row tiles of A, partial blocks of B, one-vector (matrix x vector) shape."""
+    """Ragged rows, partial 4-row tiles of A, partial blocks of B, one-vector (matrix x vector) shape; up to
+    eight rows of A take the lane-per-row kernel (any declared width whose tables fit LDS), nine the table kernel."""
     import oracle
     from sdr_amd import SDRBatch
     rng = np.random.default_rng(width + nt)
@@ -47,6 +49,10 @@ def test_inner_table_kernel_vs_oracle(width, max_len, nt, na):
     a = SDRBatch.from_csr(*a_csr, width=width, kind="arith")
     want = oracle.port().inner(oracle.Batch(*t_csr), oracle.Batch(*a_csr))
     assert np.array_equal(bits(t.inner(a)), want.view(np.uint32))
+    # an argument without payloads contributes the values of `this` alone
+    a_ids_only = SDRBatch.from_csr(a_csr[0], a_csr[1], None, width=width)
+    want_e = oracle.port().inner(oracle.Batch(*t_csr), oracle.Batch(a_csr[0], a_csr[1], None))
+    assert np.array_equal(bits(t.inner(a_ids_only)), want_e.view(np.uint32))
     # both kernels agree: the same rows without a declared width go through the merge kernel
     t0 = SDRBatch.from_csr(*t_csr, kind="arith")
     a0 = SDRBatch.from_csr(*a_csr, kind="arith")
