@@ -254,7 +254,9 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
  *
  * 1) sdrb_elem_op_count fills out_offsets[na*nb + 1] (uint32, device) with the exclusive
  *    prefix sum of the result lengths in [i][j] order and returns the total in
- *    *total (host).  Synchronises the stream.
+ *    *total (host).  Synchronises the stream.  A call may hold fewer than 2^32-1 pairs and at most
+ *    2^32-1 result elements (SDRB_ERR_OVERFLOW otherwise: split A); where the worst case of the
+ *    shapes exceeds that, the lengths are summed exactly before the limit is applied.
  * 2) the caller allocates out_ids[total] (and out_data[total] when `this` is UnitData);
  * 3) sdrb_elem_op_fill writes result (i, j) at out_offsets[i*nb + j], ascending by id.
  */

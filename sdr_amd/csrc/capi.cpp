@@ -961,11 +961,6 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
     if (op == SDRB_OP_AND) bound = from_a < from_b ? from_a : from_b;
     else if (op == SDRB_OP_RM) bound = swap_sides ? from_b : from_a;
     else bound = from_a + from_b;
-    if (bound > 0xFFFFFFFFull) {
-        set_error("result may exceed 2^32-1 elements (bound %llu); split the A batch",
-                  (unsigned long long)bound);
-        return SDRB_ERR_OVERFLOW;
-    }
     DeviceGuard guard(b->device);
     if (!guard.ok) {
         set_error("hipSetDevice(%d) failed", b->device);
@@ -976,6 +971,17 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
         rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE | SDRB_FLAG_FORCE_ROWTABLE), out_offsets,
                           b->n_rows, stream);
         if (rc != SDRB_OK) return rc;
+    }
+    if (bound > 0xFFFFFFFFull) {
+        // the bound does not rule an overflow out (intersections are usually far below it): the sizes
+        // are summed exactly, in 64 bits, before the 32-bit scan
+        uint64_t exact = 0;
+        rc = sum_u32_on_host(b->device, out_offsets, pairs, &exact, s);
+        if (rc != SDRB_OK) return rc;
+        if (exact > 0xFFFFFFFFull) {
+            set_error("result has %llu elements, more than 2^32-1; split the A batch", (unsigned long long)exact);
+            return SDRB_ERR_OVERFLOW;
+        }
     }
     SDRB_HIP(hipMemsetAsync(out_offsets + pairs, 0, sizeof(uint32_t), s));
     rc = launch_exclusive_scan_u32(b->device, out_offsets, pairs + 1, s);

@@ -185,6 +185,43 @@ void launch_swap(const FillArgs& g, bool swap) {
 
 }  // namespace
 
+namespace {
+// 64-bit sum of 32-bit counts (grid-stride, one atomic per block)
+__global__ __launch_bounds__(kBlock) void k_sum_u32(const uint32_t* __restrict__ data, uint64_t n,
+                                                    unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long wave_sum[kBlock / 64];
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) mine += data[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long block = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) block += wave_sum[w];
+        atomicAdd(total, block);
+    }
+}
+}  // namespace
+
+// exact total of `n` counts, on the host (synchronises the stream)
+int sum_u32_on_host(int device, const uint32_t* data, uint64_t n, uint64_t* total, hipStream_t stream) {
+    *total = 0;
+    if (n == 0) return SDRB_OK;
+    unsigned long long* acc = static_cast<unsigned long long*>(workspace(device, 1, sizeof(unsigned long long)));
+    if (!acc) return SDRB_ERR_HIP;
+    SDRB_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long), stream));
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_sum_u32, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, stream, data, n, acc);
+    SDRB_HIP(hipGetLastError());
+    unsigned long long host = 0;
+    SDRB_HIP(hipMemcpyAsync(&host, acc, sizeof(host), hipMemcpyDeviceToHost, stream));
+    SDRB_HIP(hipStreamSynchronize(stream));
+    *total = host;
+    return SDRB_OK;
+}
+
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream) {
     if (n == 0) return SDRB_OK;
     // single-pass scan (decoupled look-back, rocPRIM): the array is read once and written once, in place

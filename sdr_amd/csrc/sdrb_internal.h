@@ -98,6 +98,7 @@ int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64
 
 // elem_ops.hip --------------------------------------------------------------------
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream);
+int sum_u32_on_host(int device, const uint32_t* data, uint64_t n, uint64_t* total, hipStream_t stream);
 // out_ids: int32 ids, or int64 ids when the batches hold 64-bit ids
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                      const uint32_t* out_offsets, void* out_ids, float* out_data, bool rowwise,

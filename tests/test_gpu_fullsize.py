@@ -94,3 +94,28 @@ def test_element_ops_one_query_against_full_database(problem):
         for k, r in enumerate(rows):
             got = ids[int(off[r]):int(off[r + 1])]
             assert np.array_equal(got, w_ids[int(w_off[k]):int(w_off[k + 1])]), (ename, r)
+
+
+def test_ande_whose_worst_case_bound_exceeds_32_bits(problem):
+    """256 queries x 1 Mi rows: pairs x shortest row = 1.07e10 could not be indexed with 32 bits, the
+    actual intersections (0.78 ids a pair) can -- the sizes are summed exactly before the scan instead
+    of refusing the call on the bound.  Total = closed form; sampled pairs equal the oracle."""
+    q_csr, d_csr, q, d, out = problem
+    nq = 256
+    n_el = int(q_csr[0][nq])
+    sub_q = SDRBatch.from_csr(q_csr[0][:nq + 1], q_csr[1][:n_el], width=WIDTH)
+    res = sub_q.ande(d)
+    hq = np.bincount(q_csr[1][:n_el], minlength=WIDTH).astype(np.int64)
+    hd = np.bincount(d_csr[1], minlength=WIDTH).astype(np.int64)
+    assert res.total == int((hq * hd).sum())
+    rng = np.random.default_rng(5)
+    qi = np.sort(rng.choice(nq, 8, replace=False))
+    dj = np.sort(rng.choice(ND, 64, replace=False))
+    w_off, w_ids, _ = oracle.port().elem_op(oracle.AND, gather_rows(q_csr, qi), gather_rows(d_csr, dj))
+    off = res.offsets.cpu().numpy().view(np.uint32).astype(np.int64)
+    ids = res.ids.cpu().numpy()
+    for a, i in enumerate(qi):
+        for b, j in enumerate(dj):
+            p = int(i) * ND + int(j)
+            k = a * len(dj) + b
+            assert np.array_equal(ids[off[p]:off[p + 1]], w_ids[int(w_off[k]):int(w_off[k + 1])]), (i, j)
