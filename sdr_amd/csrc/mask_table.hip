@@ -518,24 +518,73 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
     }
 }
 
-// one thread per pair: insertion sort of the pair's few elements by id (payloads travel along)
+// One thread per pair puts the pair's few elements in id order (payloads travel along).  Pairs of two to
+// four elements -- nearly all that need any work -- fetch their elements together and run a sorting
+// network in registers (one round trip to memory instead of one per insertion step); longer pairs use
+// an insertion sort in place.  Ids of a pair are distinct.
+template <int N, bool DATA>
+__device__ __forceinline__ void sort_small(uint32_t lo, int32_t* __restrict__ ids, float* __restrict__ data) {
+    int32_t id[N];
+    float d[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        id[u] = ids[lo + u];
+        d[u] = DATA ? data[lo + u] : 0.0f;
+    }
+    constexpr int kNet[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};   // N = 4; N = 3 uses (0,1),(1,2),(0,1)
+    bool changed = false;
+    auto exchange = [&](int x, int y) {
+        if (id[x] > id[y]) {
+            const int32_t ti = id[x];
+            id[x] = id[y];
+            id[y] = ti;
+            const float td = d[x];
+            d[x] = d[y];
+            d[y] = td;
+            changed = true;
+        }
+    };
+    if constexpr (N == 2) {
+        exchange(0, 1);
+    } else if constexpr (N == 3) {
+        exchange(0, 1);
+        exchange(1, 2);
+        exchange(0, 1);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) exchange(kNet[c][0], kNet[c][1]);
+    }
+    if (changed) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            ids[lo + u] = id[u];
+            if constexpr (DATA) data[lo + u] = d[u];
+        }
+    }
+}
+
+template <bool DATA>
 __global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__ off, uint64_t n_pairs,
                                                     int32_t* __restrict__ ids, float* __restrict__ data) {
     const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pairs) return;
-    const uint32_t lo = off[p], hi = off[p + 1];
+    const uint32_t lo = off[p], hi = off[p + 1], n = hi - lo;
+    if (n < 2) return;
+    if (n == 2) return sort_small<2, DATA>(lo, ids, data);
+    if (n == 3) return sort_small<3, DATA>(lo, ids, data);
+    if (n == 4) return sort_small<4, DATA>(lo, ids, data);
     for (uint32_t k = lo + 1; k < hi; ++k) {
         const int32_t id = ids[k];
-        const float d = data ? data[k] : 0.0f;
+        const float d = DATA ? data[k] : 0.0f;
         uint32_t s = k;
         while (s > lo && ids[s - 1] > id) {
             ids[s] = ids[s - 1];
-            if (data) data[s] = data[s - 1];
+            if constexpr (DATA) data[s] = data[s - 1];
             --s;
         }
         if (s != k) {
             ids[s] = id;
-            if (data) data[s] = d;
+            if constexpr (DATA) data[s] = d;
         }
     }
 }
@@ -658,8 +707,11 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     SDRB_HIP(hipGetLastError());
     if (fill) {
         const uint64_t pairs = (uint64_t)na * nb;
-        hipLaunchKernelGGL(k_sort_pairs, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, stream, out_off, pairs,
-                           out_ids, math == kKeepAll ? nullptr : out_data);
+        const dim3 sort_grid((uint32_t)((pairs + 255) / 256));
+        if (math == kKeepAll)
+            hipLaunchKernelGGL(k_sort_pairs<false>, sort_grid, dim3(256), 0, stream, out_off, pairs, out_ids, nullptr);
+        else
+            hipLaunchKernelGGL(k_sort_pairs<true>, sort_grid, dim3(256), 0, stream, out_off, pairs, out_ids, out_data);
         SDRB_HIP(hipGetLastError());
     }
     return SDRB_OK;
