@@ -563,28 +563,70 @@ __device__ __forceinline__ void sort_small(uint32_t lo, int32_t* __restrict__ id
     }
 }
 
-template <bool DATA>
+// kPairsPerThread consecutive pairs per thread (four where most pairs hold fewer than three elements, else
+// one): their offsets arrive together, and the first
+// two elements of every pair that has two or more are requested together, so a thread waits once for
+// memory where a pair at a time would wait once per pair (most pairs hold fewer than three elements).
+template <bool DATA, int kPairsPerThread>
 __global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__ off, uint64_t n_pairs,
                                                     int32_t* __restrict__ ids, float* __restrict__ data) {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_pairs) return;
-    const uint32_t lo = off[p], hi = off[p + 1], n = hi - lo;
-    if (n < 2) return;
-    if (n == 2) return sort_small<2, DATA>(lo, ids, data);
-    if (n == 3) return sort_small<3, DATA>(lo, ids, data);
-    if (n == 4) return sort_small<4, DATA>(lo, ids, data);
-    for (uint32_t k = lo + 1; k < hi; ++k) {
-        const int32_t id = ids[k];
-        const float d = DATA ? data[k] : 0.0f;
-        uint32_t s = k;
-        while (s > lo && ids[s - 1] > id) {
-            ids[s] = ids[s - 1];
-            if constexpr (DATA) data[s] = data[s - 1];
-            --s;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * kPairsPerThread;
+    if (p0 >= n_pairs) return;
+    uint32_t edge[kPairsPerThread + 1];
+#pragma unroll
+    for (int u = 0; u <= kPairsPerThread; ++u) edge[u] = off[p0 + u <= n_pairs ? p0 + u : n_pairs];
+    int32_t first[kPairsPerThread], second[kPairsPerThread];
+    float dfirst[kPairsPerThread], dsecond[kPairsPerThread];
+#pragma unroll
+    for (int u = 0; u < kPairsPerThread; ++u) {
+        const uint32_t lo = edge[u], n = edge[u + 1] - lo;
+        first[u] = second[u] = 0;
+        dfirst[u] = dsecond[u] = 0.0f;
+        if (n >= 2) {
+            first[u] = ids[lo];
+            second[u] = ids[lo + 1];
+            if constexpr (DATA) {
+                dfirst[u] = data[lo];
+                dsecond[u] = data[lo + 1];
+            }
         }
-        if (s != k) {
-            ids[s] = id;
-            if constexpr (DATA) data[s] = d;
+    }
+#pragma unroll
+    for (int u = 0; u < kPairsPerThread; ++u) {
+        const uint32_t lo = edge[u], hi = edge[u + 1], n = hi - lo;
+        if (n < 2) continue;
+        if (n == 2) {
+            if (first[u] > second[u]) {
+                ids[lo] = second[u];
+                ids[lo + 1] = first[u];
+                if constexpr (DATA) {
+                    data[lo] = dsecond[u];
+                    data[lo + 1] = dfirst[u];
+                }
+            }
+            continue;
+        }
+        if (n == 3) {
+            sort_small<3, DATA>(lo, ids, data);
+            continue;
+        }
+        if (n == 4) {
+            sort_small<4, DATA>(lo, ids, data);
+            continue;
+        }
+        for (uint32_t k = lo + 1; k < hi; ++k) {
+            const int32_t id = ids[k];
+            const float d = DATA ? data[k] : 0.0f;
+            uint32_t s = k;
+            while (s > lo && ids[s - 1] > id) {
+                ids[s] = ids[s - 1];
+                if constexpr (DATA) data[s] = data[s - 1];
+                --s;
+            }
+            if (s != k) {
+                ids[s] = id;
+                if constexpr (DATA) data[s] = d;
+            }
         }
     }
 }
@@ -707,11 +749,20 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     SDRB_HIP(hipGetLastError());
     if (fill) {
         const uint64_t pairs = (uint64_t)na * nb;
-        const dim3 sort_grid((uint32_t)((pairs + 255) / 256));
-        if (math == kKeepAll)
-            hipLaunchKernelGGL(k_sort_pairs<false>, sort_grid, dim3(256), 0, stream, out_off, pairs, out_ids, nullptr);
+        // expected matches per pair: sparse results sort four pairs per thread
+        const double expected = (double)a->nnz / (double)na * ((double)b->nnz / (double)nb) / (double)width;
+        const int ppt = expected < 1.5 ? 4 : 1;
+        const dim3 sort_grid((uint32_t)((pairs + 256ull * ppt - 1) / (256ull * ppt)));
+        int32_t* const sort_ids = out_ids;
+        float* const sort_data = math == kKeepAll ? nullptr : out_data;
+        if (math == kKeepAll && ppt == 4)
+            hipLaunchKernelGGL((k_sort_pairs<false, 4>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
+        else if (math == kKeepAll)
+            hipLaunchKernelGGL((k_sort_pairs<false, 1>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
+        else if (ppt == 4)
+            hipLaunchKernelGGL((k_sort_pairs<true, 4>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
         else
-            hipLaunchKernelGGL(k_sort_pairs<true>, sort_grid, dim3(256), 0, stream, out_off, pairs, out_ids, out_data);
+            hipLaunchKernelGGL((k_sort_pairs<true, 1>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
         SDRB_HIP(hipGetLastError());
     }
     return SDRB_OK;
