@@ -119,3 +119,39 @@ def test_ande_whose_worst_case_bound_exceeds_32_bits(problem):
             p = int(i) * ND + int(j)
             k = a * len(dj) + b
             assert np.array_equal(ids[off[p]:off[p + 1]], w_ids[int(w_off[k]):int(w_off[k + 1])]), (i, j)
+
+
+def test_few_unit_queries_against_full_database():
+    """UnitData: 1 and 8 queries x 1 Mi rows -- the lane-per-row kernels for a handful of rows of A at full
+    length of B (4096 blocks striding over the rows): sizes and ande on sampled rows equal the oracle,
+    ande lengths equal ands everywhere."""
+    import torch
+    q_csr = sdr_amd.synth_csr(2, 0, 8, WIDTH, ACTIVE, True)
+    d_csr = sdr_amd.synth_csr(1, 0, ND, WIDTH, ACTIVE, True)
+    d = SDRBatch.from_csr(*d_csr, width=WIDTH)
+    rng = np.random.default_rng(11)
+    rows = np.sort(rng.choice(ND, 300, replace=False))
+    off, ids, data = d_csr
+    lens = (off[rows + 1] - off[rows]).astype(np.int64)
+    sub_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    sub_ids = np.concatenate([ids[int(off[r]):int(off[r + 1])] for r in rows])
+    sub_data = np.concatenate([data[int(off[r]):int(off[r + 1])] for r in rows])
+    sub_d = Batch(sub_off, sub_ids, sub_data)
+    for nq in (1, 8):
+        n_el = int(q_csr[0][nq])
+        q = SDRBatch.from_csr(q_csr[0][:nq + 1], q_csr[1][:n_el], q_csr[2][:n_el], width=WIDTH)
+        oq = Batch(q_csr[0][:nq + 1], q_csr[1][:n_el], q_csr[2][:n_el])
+        for op, name in enumerate(("ands", "ors", "xors", "rms")):
+            got = getattr(q, name)(d).cpu().numpy().view(np.uint32)[:, rows]
+            assert np.array_equal(got, oracle.port().size_op(op, oq, sub_d)), (nq, name)
+        res = q.ande(d)
+        sizes = q.ands(d).to(torch.int64).flatten()
+        assert bool((torch.diff(res.offsets.to(torch.int64)) == sizes).all())
+        r_off, r_ids, r_data = res.to_host()
+        w_off, w_ids, w_data = oracle.port().elem_op(oracle.AND, oq, sub_d)
+        for i in range(nq):
+            for k, r in enumerate(rows):
+                p, w = i * ND + int(r), i * len(rows) + k
+                assert np.array_equal(r_ids[int(r_off[p]):int(r_off[p + 1])], w_ids[int(w_off[w]):int(w_off[w + 1])])
+                assert np.array_equal(r_data[int(r_off[p]):int(r_off[p + 1])].view(np.uint32),
+                                      w_data[int(w_off[w]):int(w_off[w + 1])].view(np.uint32))
