@@ -83,3 +83,26 @@ def test_inner_special_values_and_rejections():
         arith.xors(arith)          # ArithData has no xor (ArithData.hpp:110-114)
     with pytest.raises(SdrbError):
         arith.ands(unit)           # ArithData and UnitData do not combine
+
+
+def test_inner_few_rows_against_a_long_database():
+    """Matrix x vector at full length (1 Mi rows): the lane-per-row kernel's blocks stride over the rows;
+    sampled entries equal the oracle bit for bit."""
+    import oracle
+    import sdr_amd
+    from sdr_amd import SDRBatch
+    nd, width, active = 1 << 20, 2048, 40
+    t_csr = sdr_amd.synth_csr(2, 0, 2, width, active, True)
+    a_csr = sdr_amd.synth_csr(1, 0, nd, width, active, True)
+    t = SDRBatch.from_csr(*t_csr, width=width, kind="arith")
+    a = SDRBatch.from_csr(*a_csr, width=width, kind="arith")
+    got = bits(t.inner(a))
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(nd, 500, replace=False))
+    off, ids, data = a_csr
+    lens = (off[rows + 1] - off[rows]).astype(np.int64)
+    sub = oracle.Batch(np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64),
+                       np.concatenate([ids[int(off[r]):int(off[r + 1])] for r in rows]),
+                       np.concatenate([data[int(off[r]):int(off[r + 1])] for r in rows]))
+    want = oracle.port().inner(oracle.Batch(*t_csr), sub)
+    assert np.array_equal(got[:, rows], want.view(np.uint32))
