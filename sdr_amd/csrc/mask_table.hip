@@ -375,9 +375,10 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
 // the eight pairs are bytes of two 32-bit registers each.  One launch, B read once, no atomics.
 // FILL: ande -- a lane walks its row in id order, so it writes the kept matches of each of its pairs
 // in order, starting at the pair's output offset (held in LDS, one column per lane).
-constexpr int kFewRows = 8;
+// ROWS: 8 (a byte per id) or 16 (two bytes per id, four count registers instead of two).
+constexpr int kFewRows = 16;
 constexpr int kFewBlock = 256;
-template <int MATH, int NQ, bool FILL>
+template <int MATH, int NQ, bool FILL, int ROWS>
 __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val,
     uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
@@ -387,13 +388,17 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
     constexpr bool NEED_A = MATH == kSelfA || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t pair_base[FILL ? kFewRows * kFewBlock : 1];   // [q][lane of the block]
-    // LDS: vals[val_cap] | bits[(width + 4) / 4] (one byte per id, entry [width] stays zero) | col[width + 1]
+    static_assert(ROWS == 8 || ROWS == 16, "a byte or two per id");
+    using bits_t = std::conditional_t<ROWS == 8, unsigned char, uint16_t>;
+    constexpr uint32_t PER_WORD = 32 / ROWS;   // ids per 32-bit word of the bit table
+    constexpr int CW = ROWS / 4;               // count registers: one byte per pair
+    __shared__ uint32_t pair_base[FILL ? ROWS * kFewBlock : 1];   // [q][lane of the block]
+    // LDS: vals[val_cap] | bits[width + 1 entries, rounded up to words] (entry [width] stays zero) | col[width + 1]
     extern __shared__ __attribute__((aligned(16))) unsigned char few_raw[];
     float* vals = reinterpret_cast<float*>(few_raw);
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(vals + val_cap);
-    const unsigned char* bits = reinterpret_cast<const unsigned char*>(bits32);
-    const uint32_t words = (width + 4) / 4;
+    const bits_t* bits = reinterpret_cast<const bits_t*>(bits32);
+    const uint32_t words = (width + PER_WORD) / PER_WORD;
     uint16_t* col = reinterpret_cast<uint16_t*>(bits32 + words);
     __shared__ uint32_t wave_tot[kFewBlock / 64];
 
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
         const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
         for (uint32_t k = tid; k < len; k += kFewBlock) {
             const uint32_t id = (uint32_t)a_ids[beg + k];
-            if (id < width) atomicOr(&bits32[id >> 2], (1u << q) << (8 * (id & 3)));   // ids outside B's width never match
+            if (id < width) atomicOr(&bits32[id / PER_WORD], (1u << q) << (ROWS * (id % PER_WORD)));   // ids outside B's width never match
         }
     }
     __syncthreads();
@@ -438,9 +443,9 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
         }
         __syncthreads();
     }
-    uint32_t la[kFewRows];
+    uint32_t la[ROWS];
 #pragma unroll
-    for (int q = 0; q < kFewRows; ++q) la[q] = (uint32_t)q < na ? a_off[q + 1] - a_off[q] : 0u;
+    for (int q = 0; q < ROWS; ++q) la[q] = (uint32_t)q < na ? a_off[q + 1] - a_off[q] : 0u;
 
     const uint64_t pieces = (nb + kFewBlock - 1) / kFewBlock;
     for (uint64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
@@ -467,7 +472,9 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
         if constexpr (FILL) {
             for (uint32_t q = 0; q < na; ++q) pair_base[q * kFewBlock + tid] = j < nb ? out_off[(uint64_t)q * nb + j] : 0u;
         }
-        uint32_t m_lo = 0, m_hi = 0, k_lo = 0, k_hi = 0;   // bytes: matches / kept matches of pairs 0..3, 4..7
+        uint32_t m_cnt[CW], k_cnt[CW];   // bytes: matches / kept matches of pairs 4w .. 4w + 3
+#pragma unroll
+        for (int w = 0; w < CW; ++w) m_cnt[w] = k_cnt[w] = 0;
 #pragma unroll
         for (int k4 = 0; k4 < NQ; ++k4) {
 #pragma unroll
@@ -487,19 +494,21 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
                         float d;
                         const uint32_t kept = match_kept_by<MATH>(va, vb, d) ? 1u : 0u;
                         const uint32_t sh = 8 * (q & 3);
+                        uint32_t kept_before = 0;
+#pragma unroll
+                        for (int w = 0; w < CW; ++w) {
+                            if ((q >> 2) == (uint32_t)w) {
+                                kept_before = (k_cnt[w] >> sh) & 0xffu;
+                                m_cnt[w] += 1u << sh;
+                                k_cnt[w] += kept << sh;
+                            }
+                        }
                         if constexpr (FILL) {
                             if (kept) {
-                                const uint32_t slot = pair_base[q * kFewBlock + tid] + (((q < 4 ? k_lo : k_hi) >> sh) & 0xffu);
+                                const uint32_t slot = pair_base[q * kFewBlock + tid] + kept_before;
                                 out_ids[slot] = (int32_t)id;
                                 if constexpr (MATH != kKeepAll) out_data[slot] = d;
                             }
-                        }
-                        if (q < 4) {
-                            m_lo += 1u << sh;
-                            k_lo += kept << sh;
-                        } else {
-                            m_hi += 1u << sh;
-                            k_hi += kept << sh;
                         }
                     } while (m != 0);
                 }
@@ -507,10 +516,10 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
         }
         uint32_t* dst = out + j;
 #pragma unroll
-        for (int q = 0; q < kFewRows; ++q) {
+        for (int q = 0; q < ROWS; ++q) {
             if constexpr (FILL) break;
-            const uint32_t mq = ((q < 4 ? m_lo : m_hi) >> (8 * (q & 3))) & 0xffu;
-            const uint32_t kq = ((q < 4 ? k_lo : k_hi) >> (8 * (q & 3))) & 0xffu;
+            const uint32_t mq = (m_cnt[q / 4] >> (8 * (q & 3))) & 0xffu;
+            const uint32_t kq = (k_cnt[q / 4] >> (8 * (q & 3))) & 0xffu;
             const uint32_t l_this = swap ? lb : la[q], l_arg = swap ? la[q] : lb;
             if ((uint32_t)q < na && j < nb) __builtin_nontemporal_store(size_of(op, l_this, l_arg, mq, kq), dst);
             dst += ld_out;
@@ -772,8 +781,9 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
 
 namespace {
 
-size_t few_lds_bytes(uint32_t width, uint32_t val_cap) {
-    return (size_t)val_cap * 4 + (size_t)((width + 4) / 4) * 4 + (size_t)(width + 2) * 2;
+size_t few_lds_bytes(uint32_t width, uint32_t val_cap, int rows) {
+    const uint32_t per_word = 32u / (uint32_t)rows;
+    return (size_t)val_cap * 4 + (size_t)((width + per_word) / per_word) * 4 + (size_t)(width + 2) * 2;
 }
 
 // the few-rows kernel takes the call when it can; *taken says whether it did
@@ -784,20 +794,27 @@ int run_few_payload(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
     if (a->n_rows > kFewRows || b->max_row_len > 64 || a->max_row_len >= 8192) return SDRB_OK;
     const uint32_t width = (uint32_t)b->width;
     const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
-    const uint32_t val_cap = (uint32_t)a->n_rows * (longest ? longest : 1u);   // < 65536: col[] is 16 bit
-    const size_t lds = few_lds_bytes(width, val_cap);
-    if (lds + (fill ? kFewRows * kFewBlock * 4 : 0) > 64 * 1024 - 256) return SDRB_OK;
+    const uint32_t val_cap = (uint32_t)a->n_rows * (longest ? longest : 1u);
+    if (val_cap > 65535u) return SDRB_OK;   // col[] is 16 bit
+    const int rows = a->n_rows <= 8 ? 8 : 16;
+    const size_t lds = few_lds_bytes(width, val_cap, rows);
+    if (lds + (fill ? (size_t)rows * kFewBlock * 4 : 0) > 64 * 1024 - 256) return SDRB_OK;
     *taken = true;
     const int math = pick_math(a, b, op, swap);
     const uint32_t quads = (b->max_row_len + 3) / 4;
     const uint64_t pieces = ((uint64_t)b->n_rows + kFewBlock - 1) / kFewBlock;
     const uint32_t per_cu = lds <= 8 * 1024 ? 8u : lds <= 16 * 1024 ? 6u : lds <= 32 * 1024 ? 4u : 2u;
     const uint32_t grid = (uint32_t)(pieces < 256ull * per_cu ? pieces : 256ull * per_cu);
-#define SDRB_FEWP_LAUNCH_NF(M, N, F)                                                                                 \
-    hipLaunchKernelGGL((k_size_few_payload<M, N, F>), dim3(grid), dim3(kFewBlock), lds, stream, a->d_offsets,        \
+#define SDRB_FEWP_LAUNCH_NFR(M, N, F, R)                                                                             \
+    hipLaunchKernelGGL((k_size_few_payload<M, N, F, R>), dim3(grid), dim3(kFewBlock), lds, stream, a->d_offsets,     \
                        a->d_ids, a->d_data, (uint32_t)a->n_rows, b->d_offsets, b->d_ids, b->d_data,                  \
                        (uint64_t)b->n_rows, width, op, swap ? 1u : 0u, val_cap, out, ld_out, out_off, out_ids,       \
                        out_data)
+#define SDRB_FEWP_LAUNCH_NF(M, N, F)                     \
+    do {                                                 \
+        if (rows == 8) SDRB_FEWP_LAUNCH_NFR(M, N, F, 8); \
+        else SDRB_FEWP_LAUNCH_NFR(M, N, F, 16);          \
+    } while (0)
 #define SDRB_FEWP_LAUNCH_N(M, N)                     \
     do {                                             \
         if (fill) SDRB_FEWP_LAUNCH_NF(M, N, true);   \
@@ -822,6 +839,7 @@ int run_few_payload(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
 #undef SDRB_FEWP_LAUNCH
 #undef SDRB_FEWP_LAUNCH_N
 #undef SDRB_FEWP_LAUNCH_NF
+#undef SDRB_FEWP_LAUNCH_NFR
     SDRB_HIP(hipGetLastError());
     return SDRB_OK;
 }

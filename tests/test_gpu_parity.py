@@ -494,10 +494,12 @@ def test_mask_table_kernel_many_tiles_and_groups(name, width, max_len):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(PAIRINGS))
 @pytest.mark.parametrize("nq,width,len_a,len_b", [(1, 2048, 40, 40), (8, 2048, 40, 40), (3, 4099, 300, 64), (5, 33, 33, 20),
-                                                  (8, 17000, 90, 7), (2, 1, 1, 1)])
+                                                  (8, 17000, 90, 7), (2, 1, 1, 1), (9, 2048, 40, 40), (16, 2049, 64, 64),
+                                                  (13, 9001, 500, 33), (16, 31, 31, 31)])
 def test_few_rows_of_a_size_kernels_vs_oracle(name, nq, width, len_a, len_b):
-    """One query (or up to eight) against a database: the one-launch kernels with a byte per row of A in
-    the table word; every op, payload pairing and orientation, ragged rows, a partial last block."""
+    """One query (or up to sixteen) against a database: the one-launch kernels with a byte (or two) per id
+    saying which rows of A hold it; every op, payload pairing and orientation, ragged rows, a partial last
+    block; ande through the same kernels (elements in id order without a sort)."""
     tu, au = PAIRINGS[name]
     rng = np.random.default_rng(7 * nq + width + 2 * tu + au)
     t = Batch(*util.ragged_rows(rng, nq, width, len_a, tu))
@@ -506,6 +508,11 @@ def test_few_rows_of_a_size_kernels_vs_oracle(name, nq, width, len_a, len_b):
     for op in range(4):
         assert np.array_equal(gpu_sizes(op, dt, da), oracle.port().size_op(op, t, a)), op
         assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), op
+    assert_elems_equal(gpu_elems(AND, dt, da), oracle.port().elem_op(AND, t, a))
+    off, ids, data = gpu_elems(AND, dt, da, swap=True)
+    w_off, w_ids, w_data = oracle.port().elem_op(AND, a, t)
+    assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
+                          util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
 
 
 @pytest.mark.gpu
