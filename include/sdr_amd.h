@@ -173,6 +173,23 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
                  uint32_t* out, uint64_t ld_out, void* stream);
 
 /*
+ * sdrb_size_op for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same results, same output
+ * layout and the same kernels as sdrb_size_op's bit-sliced path, but the bit table of A lives in a static
+ * 2 MiB + 32 KiB array of device memory inside the library instead of a workspace that grows on demand: the
+ * call makes no hipMalloc / hipFree.  Each GPU the library runs on holds its own copy of the array until the
+ * process ends; its address is looked up once per device (when a batch is first uploaded there, else on the
+ * first call).
+ * Limits: sizes that depend on ids alone (`this` EmptyData, or SDRB_OP_OR), 32-bit ids, b with a declared
+ * width <= 4096 and rows of at most 64 ids, and rows of a: at most 8192 for widths <= 2048, 4096 for widths
+ * <= 4096 (SDRB_ERR_UNSUPPORTED beyond that, before any work is enqueued).  Flags: SDRB_FLAG_SWAP.
+ * Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads) race; issue them on one stream or order them with events.
+ */
+int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                        uint32_t* out, uint64_t ld_out, void* stream);
+
+/*
  * Equality for every pair: out[i*ld_out + j] = (A_i == B_j) ? 1 : 0  -- SDR::operator== (SDR.hpp:470-483): the same
  * number of elements, the same ids position by position and, where BOTH batches carry payloads, payloads that
  * compare equal as floats (UnitData.hpp:122-124, ArithData.hpp:90-92; a payload always equals EmptyData,

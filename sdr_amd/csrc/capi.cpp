@@ -70,6 +70,12 @@ void free_batch_storage(sdrb_batch* b) {
 int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
     const bool unit = has_payload(b);
     drop_derived(b);
+    {
+        // set-up on this device (it is current here): look up where the static scratch of sdrb_size_op_static
+        // lives, so that entry point's own first call need not (it retries and reports if this failed)
+        void* unused = nullptr;
+        (void)static_scratch_resolve(b->device, &unused);
+    }
     if (b->owns_storage && b->d_offsets && b->cap_rows >= n_rows && b->cap_nnz >= nnz) return SDRB_OK;
     free_batch_storage(b);
     SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_offsets), (n_rows + 1) * sizeof(uint32_t)));
@@ -712,6 +718,36 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         if (unit_table_applicable(a, b)) return launch_size_unit_table(a, b, op, swap, out, ld_out, s);
     }
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
+}
+
+int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
+                        uint64_t ld_out, void* stream) {
+    int rc = check_pair(a, b, op);
+    if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_size_op_static");
+    if (rc != SDRB_OK) return rc;
+    if (flags & ~(SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_BITSLICE)) {
+        set_error("sdrb_size_op_static takes SDRB_FLAG_SWAP only");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH || !id_only(a, b, op, swap) ||
+        !bitslice_applicable(a, b)) {
+        set_error("sdrb_size_op_static serves the bit-sliced kernel only: sizes that depend on ids alone (`this` "
+                  "EmptyData, or ors), b with a declared width <= 4096 and rows <= 64 ids");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || ld_out < b->n_rows) {
+        set_error("sdrb_size_op_static: out is null or ld_out (%llu) < rows of b (%llu)", (unsigned long long)ld_out,
+                  (unsigned long long)b->n_rows);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_size_bitslice_static(a, b, op, swap, out, ld_out, static_cast<hipStream_t>(stream));
 }
 
 int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream) {

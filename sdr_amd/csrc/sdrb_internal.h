@@ -86,6 +86,13 @@ bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b);
 int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                          uint32_t* out, uint64_t ld_out, hipStream_t stream);
 
+// The same kernels with the bit table in a file-scope __device__ array instead of the growing workspace
+// (no hipMalloc anywhere on the path); static_scratch_resolve looks the array's address up once per device,
+// with that device current.
+int static_scratch_resolve(int device, void** ptr);
+int launch_size_bitslice_static(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
+                                uint64_t ld_out, hipStream_t stream);
+
 // size_merge.hip ------------------------------------------------------------------
 // rowwise: result j = A_j.op(B_j) for two batches of equal length, out[j]
 // (both batches hold ids of the same width: 32 or 64 bits)

@@ -15,6 +15,7 @@
 // unpacked four counts at a time into bytes and stored as uint32, one 256-byte coalesced
 // store per wave per A row.  Each row of B is read from HBM once; the output write
 // (4 bytes per pair) is the only large stream, so the kernel is bound by HBM write bandwidth.
+#include <mutex>
 #include <type_traits>
 
 #include "bitslice_device.h"
@@ -22,6 +23,15 @@
 namespace sdrb {
 
 namespace {
+
+// Scratch of the entry point that allocates nothing (sdrb_size_op_static): the bit table of A and the
+// lengths of its rows.  Every GPU the library runs on holds its own copy of this array until the process
+// ends.  In host code the name is only a handle for hipGetSymbolAddress, never a device address.
+constexpr size_t kStaticScratchBytes = (2u << 20) + (32u << 10);
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+void* g_static_ptr[kMaxDevices];   // device address of `scratch` on each device, resolved once
 
 // One tile: gather the row's table words from LDS buffer `buf`, count, unpack, store.
 // `rows_in_tile` < 64 only for the last tile of A; stores to the missing rows are switched
@@ -304,8 +314,10 @@ bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b) {
     return make_plan(a, b, &p);
 }
 
-int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
-                         uint32_t* out, uint64_t ld_out, hipStream_t stream) {
+namespace {
+// ws_fixed: caller-provided scratch of ws_fixed_bytes (the static array); null: the growing workspace
+int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
+                            uint64_t ld_out, hipStream_t stream, char* ws_fixed, size_t ws_fixed_bytes) {
     Plan plan;
     if (!make_plan(a, b, &plan)) {
         set_error("bit-sliced size kernel not applicable (needs 0 < width <= 4096 and rows <= 64 ids on the streamed batch)");
@@ -351,8 +363,18 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     g.ntiles = (uint32_t)((a->n_rows + kTileRows - 1) / kTileRows);
     const size_t table_bytes = (size_t)g.ntiles * plan.wcap * sizeof(u64);
     const size_t len_bytes = (size_t)g.ntiles * kTileRows * sizeof(uint32_t);
-    char* ws = static_cast<char*>(workspace(b->device, 0, table_bytes + len_bytes));
-    if (!ws) return SDRB_ERR_HIP;
+    char* ws = ws_fixed;
+    if (ws_fixed) {
+        if (table_bytes + len_bytes > ws_fixed_bytes) {
+            set_error("sdrb_size_op_static: %llu rows of A need %zu bytes of table, the static scratch holds %zu "
+                      "(at most %zu rows at this width)", (unsigned long long)a->n_rows, table_bytes + len_bytes,
+                      ws_fixed_bytes, ws_fixed_bytes / ((size_t)plan.wcap * sizeof(u64) + kTileRows * sizeof(uint32_t)) * kTileRows);
+            return SDRB_ERR_UNSUPPORTED;
+        }
+    } else {
+        ws = static_cast<char*>(workspace(b->device, 0, table_bytes + len_bytes));
+        if (!ws) return SDRB_ERR_HIP;
+    }
     SDRB_HIP(hipMemsetAsync(ws, 0, table_bytes + len_bytes, stream));
     u64* table = reinterpret_cast<u64*>(ws);
     uint32_t* a_len = reinterpret_cast<uint32_t*>(ws + table_bytes);
@@ -396,6 +418,37 @@ int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     }
     SDRB_HIP(hipGetLastError());
     return SDRB_OK;
+}
+}  // namespace
+
+int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
+                         uint32_t* out, uint64_t ld_out, hipStream_t stream) {
+    return launch_size_bitslice_ws(a, b, op, swap, out, ld_out, stream, nullptr, 0);
+}
+
+// Device address of the static scratch on `device`, which must be the current device.  The first call on a
+// device asks the runtime for it (a lookup in the loaded code object, no allocation); later calls read a table.
+int static_scratch_resolve(int device, void** ptr) {
+    if (device < 0 || device >= kMaxDevices) {
+        set_error("device %d is outside the %d devices the static scratch is tracked for", device, kMaxDevices);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_ptr[device]) {
+        void* p = nullptr;
+        SDRB_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_static_ptr[device] = p;
+    }
+    *ptr = g_static_ptr[device];
+    return SDRB_OK;
+}
+
+int launch_size_bitslice_static(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
+                                uint64_t ld_out, hipStream_t stream) {
+    void* ptr = nullptr;
+    const int rc = static_scratch_resolve(b->device, &ptr);
+    if (rc != SDRB_OK) return rc;
+    return launch_size_bitslice_ws(a, b, op, swap, out, ld_out, stream, static_cast<char*>(ptr), kStaticScratchBytes);
 }
 
 }  // namespace sdrb
