@@ -229,7 +229,7 @@ int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t 
     // the transposed bit table of the candidates (same table and scratch slot as the size kernel)
     const size_t table_bytes = (size_t)g.ntiles * wcap * sizeof(u64);
     const size_t len_bytes = (size_t)g.ntiles * kTileRows * sizeof(uint32_t);
-    char* ws = static_cast<char*>(workspace(b->device, 0, table_bytes + len_bytes));
+    char* ws = static_cast<char*>(workspace(b->device, stream, 0, table_bytes + len_bytes));
     if (!ws) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemsetAsync(ws, 0, table_bytes + len_bytes, stream));
     if (b->n_rows) {
@@ -254,7 +254,7 @@ int launch_allpairs_bitslice(const sdrb_batch* a, const sdrb_batch* b, uint32_t 
     splits = g.ntiles ? (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split : 1u;
     g.grid = dim3(gx, splits);
 
-    int* partial = static_cast<int*>(workspace(b->device, 4, (size_t)a->n_rows * splits * LIST * sizeof(int)));
+    int* partial = static_cast<int*>(workspace(b->device, stream, 4, (size_t)a->n_rows * splits * LIST * sizeof(int)));
     if (!partial) return SDRB_ERR_HIP;
     g.partial = partial;
     switch (nch) {

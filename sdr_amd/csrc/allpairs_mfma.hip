@@ -372,8 +372,9 @@ uint32_t chunks_of(const sdrb_batch* b) { return (uint32_t)((b->width + kChunk -
 // builds (or reuses) the fragment-ordered byte matrix of a batch, `n_chunks` chunks wide
 int ensure_dense(const sdrb_batch* b, uint32_t n_chunks, hipStream_t stream) {
     sdrb_batch* mb = const_cast<sdrb_batch*>(b);
-    if (mb->d_dense8 && mb->dense_chunks == n_chunks) return SDRB_OK;
+    if (mb->d_dense8 && mb->dense_chunks == n_chunks) return derived_wait(mb->dense_ready, mb->dense_stream, stream);
     if (mb->d_dense8) {
+        if (mb->dense_stream != stream) SDRB_HIP(hipStreamSynchronize(mb->dense_stream));
         SDRB_HIP(hipStreamSynchronize(stream));
         (void)hipFree(mb->d_dense8);
         mb->d_dense8 = nullptr;
@@ -391,7 +392,7 @@ int ensure_dense(const sdrb_batch* b, uint32_t n_chunks, hipStream_t stream) {
     hipLaunchKernelGGL(k_densify, dim3((uint32_t)((b->n_rows + 3) / 4)), dim3(256), 0, stream, b->d_offsets,
                        b->d_ids, (uint32_t)b->n_rows, n_chunks, mb->d_dense8);
     SDRB_HIP(hipGetLastError());
-    return SDRB_OK;
+    return derived_built(&mb->dense_ready, &mb->dense_stream, stream);
 }
 
 template <int LIST>
@@ -419,7 +420,7 @@ int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint
     }
     const uint32_t ipanels_pad = (n_ipanels + 7) / 8 * 8;
     const size_t pbytes = (size_t)n_ipanels * kPanel * splits * kSubLists * LIST * sizeof(int);
-    int* partial = static_cast<int*>(workspace(b->device, 4, pbytes));
+    int* partial = static_cast<int*>(workspace(b->device, stream, 4, pbytes));
     if (!partial) return SDRB_ERR_HIP;
     hipLaunchKernelGGL(k_allpairs_mfma<LIST>, dim3(ipanels_pad * splits), dim3(256), 0, stream,
                        reinterpret_cast<const i32x4*>(a->d_dense8), reinterpret_cast<const i32x4*>(b->d_dense8),

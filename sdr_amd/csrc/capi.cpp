@@ -8,6 +8,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "sdrb_internal.h"
@@ -30,12 +31,47 @@ struct DeviceGuard {
     }
 };
 
+// Scratch blocks are keyed by (device, stream, slot): work enqueued on different streams -- or by different
+// host threads, each on its own stream -- never shares a block.  A block that has become too small is retired
+// behind an event on its stream and freed once that event has completed, so growth synchronises nothing.
 struct Scratch {
     void* ptr = nullptr;
     size_t bytes = 0;
 };
+struct Retired {
+    int device;
+    void* ptr;
+    hipEvent_t done;
+};
+struct ScratchKey {
+    int device;
+    hipStream_t stream;
+    int slot;
+    bool operator<(const ScratchKey& o) const {
+        if (device != o.device) return device < o.device;
+        if (stream != o.stream) return stream < o.stream;
+        return slot < o.slot;
+    }
+};
 std::mutex g_ws_mutex;
-std::map<std::pair<int, int>, Scratch> g_ws;
+std::map<ScratchKey, Scratch> g_ws;
+std::vector<Retired> g_retired;
+
+// frees the retired blocks of `device` (the current device) whose last users have finished; g_ws_mutex held
+void reap_retired(int device) {
+    for (size_t k = 0; k < g_retired.size();) {
+        Retired& r = g_retired[k];
+        if (r.device == device && hipEventQuery(r.done) == hipSuccess) {
+            (void)hipEventDestroy(r.done);
+            (void)hipFree(r.ptr);
+            g_retired[k] = g_retired.back();
+            g_retired.pop_back();
+        } else {
+            ++k;
+        }
+    }
+    (void)hipGetLastError();   // hipErrorNotReady of a pending event is not an error
+}
 
 // Data derived from the rows (bit planes, dense byte matrix) dies with the content it was built from.
 void drop_derived(sdrb_batch* b) {
@@ -43,6 +79,9 @@ void drop_derived(sdrb_batch* b) {
     if (b->d_dense8) (void)hipFree(b->d_dense8);
     b->d_bitplanes = nullptr;
     b->d_dense8 = nullptr;
+    if (b->bitplanes_ready) (void)hipEventDestroy(b->bitplanes_ready);
+    if (b->dense_ready) (void)hipEventDestroy(b->dense_ready);
+    b->bitplanes_ready = b->dense_ready = nullptr;
 }
 
 void free_batch_storage(sdrb_batch* b) {
@@ -194,10 +233,16 @@ struct IdView {
     ~IdView() {
         // only what was built through THIS view is handed back (two views of one batch may be alive at once)
         sdrb_batch* m = const_cast<sdrb_batch*>(src);
-        if (v.d_bitplanes != src->d_bitplanes && v.d_bitplanes) m->d_bitplanes = v.d_bitplanes;
+        if (v.d_bitplanes != src->d_bitplanes && v.d_bitplanes) {
+            m->d_bitplanes = v.d_bitplanes;
+            m->bitplanes_ready = v.bitplanes_ready;
+            m->bitplanes_stream = v.bitplanes_stream;
+        }
         if (v.d_dense8 != src->d_dense8 && v.d_dense8) {
             m->d_dense8 = v.d_dense8;
             m->dense_chunks = v.dense_chunks;
+            m->dense_ready = v.dense_ready;
+            m->dense_stream = v.dense_stream;
         }
     }
 };
@@ -227,18 +272,27 @@ void set_error(const char* fmt, ...) {
     g_error = buf;
 }
 
-void* workspace(int device, int slot, size_t bytes) {
+void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fresh) {
+    if (fresh) *fresh = false;
     std::lock_guard<std::mutex> lock(g_ws_mutex);
-    Scratch& s = g_ws[{device, slot}];
+    if (!g_retired.empty()) reap_retired(device);
+    Scratch& s = g_ws[ScratchKey{device, stream, slot}];
     if (s.bytes >= bytes && s.ptr) return s.ptr;
     if (s.ptr) {
-        // earlier kernels on any stream may still read the old block
-        (void)hipDeviceSynchronize();
-        (void)hipFree(s.ptr);
+        // kernels already enqueued on this stream may still read the old block: it is freed after them
+        Retired r{device, s.ptr, nullptr};
+        if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess &&
+            hipEventRecord(r.done, stream) == hipSuccess) {
+            g_retired.push_back(r);
+        } else {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(s.ptr);
+        }
         s.ptr = nullptr;
         s.bytes = 0;
     }
-    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    // grow by at least half so that a sequence of slowly growing requests settles quickly
+    size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
     hipError_t e = hipMalloc(&s.ptr, want);
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu) for workspace failed: %s", want, hipGetErrorString(e));
@@ -246,6 +300,7 @@ void* workspace(int device, int slot, size_t bytes) {
         return nullptr;
     }
     s.bytes = want;
+    if (fresh) *fresh = true;
     return s.ptr;
 }
 
@@ -506,7 +561,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
         }
     }
     PackStats init{0u, INT32_MAX, INT32_MIN, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-    PackStats* d_st = static_cast<PackStats*>(workspace(batch->device, 2, sizeof(PackStats)));
+    PackStats* d_st = static_cast<PackStats*>(workspace(batch->device, s, 2, sizeof(PackStats)));
     if (!d_st) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemcpyAsync(d_st, &init, sizeof init, hipMemcpyHostToDevice, s));
     // one pass over the rows: total element count, row checks, id span (grid covers >= 1 thread)
@@ -818,6 +873,24 @@ int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
 }
 
 namespace {
+// counts[0..pairs) -> exclusive offsets[0..pairs] in place, the exact total to the host (synchronises);
+// a result of 2^32 elements or more cannot be addressed by the 32-bit offsets
+int finish_count(int device, uint32_t* out_offsets, uint64_t pairs, uint64_t* total, hipStream_t s) {
+    unsigned long long* total_dev = static_cast<unsigned long long*>(sdrb::workspace(device, s, 10, sizeof(unsigned long long)));
+    if (!total_dev) return SDRB_ERR_HIP;
+    const int rc = sdrb::launch_exclusive_scan_u32(device, out_offsets, pairs + 1, pairs, total_dev, s);
+    if (rc != SDRB_OK) return rc;
+    unsigned long long t64 = 0;
+    SDRB_HIP(hipMemcpyAsync(&t64, total_dev, sizeof t64, hipMemcpyDeviceToHost, s));
+    SDRB_HIP(hipStreamSynchronize(s));
+    if (t64 > 0xFFFFFFFFull) {
+        sdrb::set_error("result has %llu elements, more than 2^32-1; split the A batch", t64);
+        return SDRB_ERR_OVERFLOW;
+    }
+    *total = t64;
+    return SDRB_OK;
+}
+
 int check_queries(const sdrb_batch* b, uint64_t n, const int32_t* lo, const int32_t* hi, bool ranges) {
     if (!b || !b->d_offsets) {
         sdrb::set_error("null batch handle or no uploaded rows");
@@ -868,8 +941,8 @@ int sdrb_range_elems_count(const sdrb_batch* b, uint64_t n_ranges, const int32_t
         return SDRB_ERR_INVALID_ARG;
     }
     const uint64_t pairs = n_ranges * b->n_rows;
-    if (pairs >= 0xFFFFFFFFull || n_ranges * b->nnz > 0xFFFFFFFFull) {
-        set_error("result may exceed 2^32-1 pairs or elements; use fewer ranges per call");
+    if (pairs >= 0xFFFFFFFFull) {
+        set_error("too many (range, row) pairs for one call; use fewer ranges per call");
         return SDRB_ERR_OVERFLOW;
     }
     DeviceGuard guard(b->device);
@@ -878,14 +951,7 @@ int sdrb_range_elems_count(const sdrb_batch* b, uint64_t n_ranges, const int32_t
         rc = launch_range_query(b, 0, n_ranges, lo, hi, out_offsets, b->n_rows, nullptr, nullptr, nullptr, s);
         if (rc != SDRB_OK) return rc;
     }
-    SDRB_HIP(hipMemsetAsync(out_offsets + pairs, 0, sizeof(uint32_t), s));
-    rc = launch_exclusive_scan_u32(b->device, out_offsets, pairs + 1, s);
-    if (rc != SDRB_OK) return rc;
-    uint32_t t32 = 0;
-    SDRB_HIP(hipMemcpyAsync(&t32, out_offsets + pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    SDRB_HIP(hipStreamSynchronize(s));
-    *total = t32;
-    return SDRB_OK;
+    return finish_count(b->device, out_offsets, pairs, total, s);
 }
 
 int sdrb_range_elems_fill(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
@@ -990,13 +1056,12 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
         set_error("too many pairs for one call (%llu)", (unsigned long long)pairs);
         return SDRB_ERR_OVERFLOW;
     }
-    // an upper bound of the total keeps the 32-bit scan exact
-    const bool swap_sides = (flags & SDRB_FLAG_SWAP) != 0;
-    const uint64_t from_a = rowwise ? a->nnz : a->nnz * b->n_rows, from_b = rowwise ? b->nnz : b->nnz * a->n_rows;
-    uint64_t bound;
-    if (op == SDRB_OP_AND) bound = from_a < from_b ? from_a : from_b;
-    else if (op == SDRB_OP_RM) bound = swap_sides ? from_b : from_a;
-    else bound = from_a + from_b;
+    // the scan carries sums in 62 bits: no result can come near that (every element is output at most
+    // once per row of the other batch)
+    if ((unsigned __int128)a->nnz * b->n_rows + (unsigned __int128)b->nnz * a->n_rows >= ((unsigned __int128)1 << 61)) {
+        set_error("result far beyond 2^32-1 elements; split the A batch");
+        return SDRB_ERR_OVERFLOW;
+    }
     DeviceGuard guard(b->device);
     if (!guard.ok) {
         set_error("hipSetDevice(%d) failed", b->device);
@@ -1008,25 +1073,7 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
                           b->n_rows, stream);
         if (rc != SDRB_OK) return rc;
     }
-    if (bound > 0xFFFFFFFFull) {
-        // the bound does not rule an overflow out (intersections are usually far below it): the sizes
-        // are summed exactly, in 64 bits, before the 32-bit scan
-        uint64_t exact = 0;
-        rc = sum_u32_on_host(b->device, out_offsets, pairs, &exact, s);
-        if (rc != SDRB_OK) return rc;
-        if (exact > 0xFFFFFFFFull) {
-            set_error("result has %llu elements, more than 2^32-1; split the A batch", (unsigned long long)exact);
-            return SDRB_ERR_OVERFLOW;
-        }
-    }
-    SDRB_HIP(hipMemsetAsync(out_offsets + pairs, 0, sizeof(uint32_t), s));
-    rc = launch_exclusive_scan_u32(b->device, out_offsets, pairs + 1, s);
-    if (rc != SDRB_OK) return rc;
-    uint32_t t32 = 0;
-    SDRB_HIP(hipMemcpyAsync(&t32, out_offsets + pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    SDRB_HIP(hipStreamSynchronize(s));
-    *total = t32;
-    return SDRB_OK;
+    return finish_count(b->device, out_offsets, pairs, total, s);
 }
 
 namespace {
@@ -1085,10 +1132,22 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         }
         return launch_elem_rank(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }
+    if (flags & (SDRB_FLAG_FORCE_BITMAP | SDRB_FLAG_FORCE_LANEMERGE)) {
+        const bool bitmap = (flags & SDRB_FLAG_FORCE_BITMAP) != 0;
+        if (rowwise || a->id_bits != 32 ||
+            !(bitmap ? elem_bitmap_applicable(a, b, swap) : elem_lanemerge_applicable(a, b, op, swap))) {
+            set_error("the requested element fill kernel does not apply to these batches / this op");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return bitmap ? launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s)
+                      : launch_elem_lanemerge(a, b, op, swap, out_offsets, out_ids, s);
+    }
     if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32) {
         // intersections are small: visiting only the matches (mask table) beats enumerating whole bitsets
         if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && mask_table_applicable(a, b))
             return launch_elem_mask_table(a, b, swap, out_offsets, out_ids, out_data, s);
+        // unions of short rows, ids only: a lane per pair, coalesced runs out of an LDS stage
+        if (elem_lanemerge_applicable(a, b, op, swap)) return launch_elem_lanemerge(a, b, op, swap, out_offsets, out_ids, s);
         if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
         if (unit_table_fill_applicable(a, b, op, swap))
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);

@@ -466,7 +466,7 @@ template <typename WORD>
 int run(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_off,
         int32_t* out_ids, hipStream_t stream) {
     const size_t bytes = (size_t)a->n_rows * 64 * sizeof(WORD);
-    WORD* bits = static_cast<WORD*>(workspace(b->device, 3, bytes));
+    WORD* bits = static_cast<WORD*>(workspace(b->device, stream, 3, bytes));
     if (!bits) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemsetAsync(bits, 0, bytes, stream));
     hipLaunchKernelGGL(k_build_bitsets<WORD>, dim3((uint32_t)a->n_rows), dim3(64), 0, stream,

@@ -948,7 +948,7 @@ int launch_elem_rank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
     const bool is_union = op == SDRB_OP_OR || op == SDRB_OP_XOR;
     const Shape shape = shape_for(a, b, is_union || swap, is_union || !swap);
     const uint32_t nw = shape.nw;
-    RankEntry* a_tab = static_cast<RankEntry*>(workspace(b->device, 9, (size_t)a->n_rows * nw * sizeof(RankEntry)));
+    RankEntry* a_tab = static_cast<RankEntry*>(workspace(b->device, stream, 9, (size_t)a->n_rows * nw * sizeof(RankEntry)));
     if (!a_tab) return SDRB_ERR_HIP;
     hipLaunchKernelGGL(k_build_rank_tables, dim3((uint32_t)a->n_rows), dim3(kBlock), nw * sizeof(uint32_t), stream,
                        a->d_offsets, a->d_ids, nw, a_tab);

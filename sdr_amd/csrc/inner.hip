@@ -369,7 +369,7 @@ int launch_inner(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t 
     g.na = (uint32_t)a->n_rows;
     g.ntiles = (uint32_t)((a->n_rows + 3) / 4);
     const size_t table_bytes = (size_t)g.ntiles * wcap * sizeof(f32x4);
-    float* table = static_cast<float*>(workspace(b->device, 5, table_bytes));
+    float* table = static_cast<float*>(workspace(b->device, stream, 5, table_bytes));
     if (!table) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemsetAsync(table, 0, table_bytes, stream));
     hipLaunchKernelGGL(k_build_value_table, dim3((uint32_t)a->n_rows), dim3(64), 0, stream, a->d_offsets, a->d_ids,

@@ -697,7 +697,7 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     float* dense = nullptr;
     if (need_a && !flat) {
         const size_t bytes = (size_t)na * width * sizeof(float);
-        dense = static_cast<float*>(workspace(b->device, 6, bytes));
+        dense = static_cast<float*>(workspace(b->device, stream, 6, bytes));
         if (!dense) return SDRB_ERR_HIP;
         // only entries the mask points at are ever read, so the matrix needs no clearing
         hipLaunchKernelGGL(k_scatter_values, dim3(na), dim3(64), 0, stream, a->d_offsets, a->d_ids, a->d_data, width,

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void k_range_query(
 // host query arrays -> device scratch (slot 7), ordered on the stream
 int stage_queries(int device, uint64_t n, const int32_t* lo, const int32_t* hi, const int32_t** d_lo,
                   const int32_t** d_hi, hipStream_t stream) {
-    int32_t* ws = static_cast<int32_t*>(workspace(device, 7, 2 * n * sizeof(int32_t)));
+    int32_t* ws = static_cast<int32_t*>(workspace(device, stream, 7, 2 * n * sizeof(int32_t)));
     if (!ws) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemcpyAsync(ws, lo, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (hi) SDRB_HIP(hipMemcpyAsync(ws + n, hi, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));

@@ -29,6 +29,10 @@ struct sdrb_batch {
     uint32_t* d_bitplanes = nullptr;  // derived, built on demand: word w of row j at [w*n_rows + j]
     uint8_t* d_dense8 = nullptr;      // derived, built on demand: 0/1 bytes in MFMA fragment order (allpairs_mfma.hip)
     uint32_t dense_chunks = 0;        // width of d_dense8 in 64-id chunks
+    // A derived form is built on the stream of the call that first needs it; the event marks the end of that
+    // build, and a call on any other stream waits for it before its kernels read the form.
+    hipEvent_t bitplanes_ready = nullptr, dense_ready = nullptr;
+    hipStream_t bitplanes_stream = nullptr, dense_stream = nullptr;
 };
 
 namespace sdrb {
@@ -56,12 +60,14 @@ int guarded(const char* what, F&& body) noexcept {
     }
 }
 
-// Per-device scratch that grows on demand and lives until process exit.
+// Scratch per (device, stream, slot) that grows on demand and lives until process exit: calls on different
+// streams never share a block, and a block is reused only by later work on the same stream.
 // slot 0: query bit-table; slot 1: scan block sums; slot 2: pack statistics; slot 3: bitsets of A;
 // slot 4: partial top-k lists; slot 5: interleaved value table of A (dot products);
 // slot 6: dense payload matrix of A (mask-table kernel); slot 7: staged range / point queries;
 // slot 8: sort buffers of the transpose; slot 9: rank tables of A (wave-per-pair element fill).
-void* workspace(int device, int slot, size_t bytes);
+// *fresh (optional) tells whether the block has just been allocated, i.e. holds nothing of an earlier call.
+void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fresh = nullptr);
 
 #define SDRB_HIP(call)                                                                   \
     do {                                                                                 \
@@ -72,6 +78,19 @@ void* workspace(int device, int slot, size_t bytes);
             return SDRB_ERR_HIP;                                                         \
         }                                                                                \
     } while (0)
+
+// after the build of a derived form has been enqueued on `stream`
+inline int derived_built(hipEvent_t* ready, hipStream_t* built_on, hipStream_t stream) {
+    if (!*ready) SDRB_HIP(hipEventCreateWithFlags(ready, hipEventDisableTiming));
+    SDRB_HIP(hipEventRecord(*ready, stream));
+    *built_on = stream;
+    return SDRB_OK;
+}
+// before kernels on `stream` read a derived form that another stream may still be building
+inline int derived_wait(hipEvent_t ready, hipStream_t built_on, hipStream_t stream) {
+    if (ready && built_on != stream) SDRB_HIP(hipStreamWaitEvent(stream, ready, 0));
+    return SDRB_OK;
+}
 
 // How a pair's result depends on payloads, after SDRB_FLAG_SWAP has been applied:
 // `this_unit` / `arg_unit` say whether the `this` / `arg` side carries UnitData.
@@ -104,8 +123,11 @@ int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64
                  hipStream_t stream);
 
 // elem_ops.hip --------------------------------------------------------------------
-int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, hipStream_t stream);
-int sum_u32_on_host(int device, const uint32_t* data, uint64_t n, uint64_t* total, hipStream_t stream);
+// In-place exclusive prefix sum of data[0..n) in one pass; entries at index >= n_valid count as zero (so a
+// scan over n = pairs + 1, n_valid = pairs leaves the total in data[pairs] without clearing it first).
+// Offsets are kept modulo 2^32; the exact 64-bit sum goes to *total_dev (device memory, may be null).
+int launch_exclusive_scan_u32(int device, uint32_t* data, uint64_t n, uint64_t n_valid,
+                              unsigned long long* total_dev, hipStream_t stream);
 // out_ids: int32 ids, or int64 ids when the batches hold 64-bit ids
 int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                      const uint32_t* out_offsets, void* out_ids, float* out_data, bool rowwise,
@@ -120,6 +142,12 @@ int launch_elem_visit(const sdrb_batch* a, const sdrb_batch* b, int op, bool swa
 bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);
 int launch_elem_bitmap(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                        const uint32_t* out_offsets, int32_t* out_ids, hipStream_t stream);
+
+// elem_lanemerge.hip ---------------------------------------------------------------
+// ore / xore / rme with id-only results on short rows: a lane per pair, outputs staged in LDS per wave.
+bool elem_lanemerge_applicable(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap);
+int launch_elem_lanemerge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
+                          int32_t* out_ids, hipStream_t stream);
 
 // elem_rank.hip --------------------------------------------------------------------
 // Wave-per-pair fill from rank tables (bitset + popcount prefix per row): any payload kinds, all four

@@ -372,7 +372,7 @@ int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bo
             return SDRB_ERR_UNSUPPORTED;
         }
     } else {
-        ws = static_cast<char*>(workspace(b->device, 0, table_bytes + len_bytes));
+        ws = static_cast<char*>(workspace(b->device, stream, 0, table_bytes + len_bytes));
         if (!ws) return SDRB_ERR_HIP;
     }
     SDRB_HIP(hipMemsetAsync(ws, 0, table_bytes + len_bytes, stream));

@@ -117,7 +117,7 @@ bool popcount_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 
 int ensure_bitplanes(const sdrb_batch* b, hipStream_t stream) {
     sdrb_batch* mb = const_cast<sdrb_batch*>(b);   // derived data cached in the handle
-    if (mb->d_bitplanes) return SDRB_OK;
+    if (mb->d_bitplanes) return derived_wait(mb->bitplanes_ready, mb->bitplanes_stream, stream);
     const int nw = words_for(b->width);
     const size_t bytes = (size_t)nw * b->n_rows * sizeof(uint32_t);
     SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&mb->d_bitplanes), bytes));
@@ -125,7 +125,7 @@ int ensure_bitplanes(const sdrb_batch* b, hipStream_t stream) {
     hipLaunchKernelGGL(k_scatter_bitplanes, dim3((uint32_t)((b->n_rows + 3) / 4)), dim3(256), 0, stream,
                        b->d_offsets, b->d_ids, (uint32_t)b->n_rows, mb->d_bitplanes);
     SDRB_HIP(hipGetLastError());
-    return SDRB_OK;
+    return derived_built(&mb->bitplanes_ready, &mb->bitplanes_stream, stream);
 }
 
 int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
@@ -140,7 +140,7 @@ int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     const int nw = words_for(b->width);
     const size_t bits_bytes = (size_t)a->n_rows * nw * sizeof(uint32_t);
     const size_t len_bytes = (size_t)a->n_rows * sizeof(uint32_t);
-    char* ws = static_cast<char*>(workspace(b->device, 0, bits_bytes + len_bytes));
+    char* ws = static_cast<char*>(workspace(b->device, stream, 0, bits_bytes + len_bytes));
     if (!ws) return SDRB_ERR_HIP;
     SDRB_HIP(hipMemsetAsync(ws, 0, bits_bytes + len_bytes, stream));
     uint32_t* a_bits = reinterpret_cast<uint32_t*>(ws);

@@ -65,7 +65,7 @@ int launch_transpose(const sdrb_batch* src, uint32_t* dst_off, int32_t* dst_ids,
     SDRB_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                        (uint32_t*)nullptr, nnz, 0, bits, stream));
     const size_t arr = (nnz * sizeof(uint32_t) + 255) / 256 * 256;
-    char* ws = static_cast<char*>(workspace(src->device, 8, 4 * arr + temp_bytes));
+    char* ws = static_cast<char*>(workspace(src->device, stream, 8, 4 * arr + temp_bytes));
     if (!ws) return SDRB_ERR_HIP;
     uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws);
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + arr);
@@ -76,7 +76,7 @@ int launch_transpose(const sdrb_batch* src, uint32_t* dst_off, int32_t* dst_ids,
                        n_rows, keys_in, elem_in, dst_off);
     SDRB_HIP(hipGetLastError());
     // column counts -> column offsets (the extra last entry is zero, so the scan's last value is nnz)
-    int rc = launch_exclusive_scan_u32(src->device, dst_off, (uint64_t)width + 1, stream);
+    int rc = launch_exclusive_scan_u32(src->device, dst_off, (uint64_t)width + 1, (uint64_t)width, nullptr, stream);
     if (rc != SDRB_OK) return rc;
     SDRB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, elem_in, elem_out, nnz, 0, bits, stream));
     hipLaunchKernelGGL(k_gather_transposed, dim3((uint32_t)((nnz + 255) / 256)), dim3(256), 0, stream, src->d_offsets,

@@ -242,6 +242,15 @@ def test_bitset_element_kernel_vs_oracle(width, max_len, au):
         want = oracle.port().elem_op(op, t, a)
         assert_elems_equal(gpu_elems(op, dt, da), want)
         assert_elems_equal(gpu_elems(op, dt, da, algo="merge"), want)
+        assert_elems_equal(gpu_elems(op, dt, da, algo="bitmap"), want)
+        if op != AND:   # unions of short rows: a lane per pair (rows of 100 ids do not fit its LDS stage)
+            try:
+                got = gpu_elems(op, dt, da, algo="lanemerge")
+            except sdr_amd.SdrbError as e:
+                assert e.code == -5 and max_len > 64
+            else:
+                assert max_len <= 64
+                assert_elems_equal(got, want)
     # swapped roles: this = rows of the second batch
     b2 = Batch(*util.ragged_rows(rng, 300, width, max_len))
     db2 = dev(b2, width)
@@ -553,3 +562,25 @@ def test_64_bit_batches_are_refused_where_not_supported():
     with pytest.raises(sdr_amd.SdrbError) as e:
         SDRBatch.from_csr(np.array([0, 2], np.uint64), np.array([5, 5], np.int64))
     assert e.value.code == -2
+
+
+def test_lanemerge_fill_signed_ids_chunks_of_a_and_sentinel():
+    # ids of any sign without a declared width (32-bit staging), more rows of A than one block's chunk, a ragged
+    # last wave of B; an id equal to INT32_MAX would collide with the row terminator, so such batches go elsewhere
+    rng = np.random.default_rng(99)
+    t = Batch(*util.ragged_rows(rng, 300, 5000, 40, lo=-2500))
+    a = Batch(*util.ragged_rows(rng, 1111, 5000, 40, lo=-2500))
+    dt, da = dev(t, 0), dev(a, 0)
+    for op in (OR, XOR, RM):
+        want = oracle.port().elem_op(op, t, a)
+        assert_elems_equal(gpu_elems(op, dt, da, algo="lanemerge"), want)
+        assert_elems_equal(gpu_elems(op, dt, da), want)
+        off, ids, data = gpu_elems(op, dt, da, swap=True, algo="lanemerge")
+        w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
+        assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
+                              util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
+    top = Batch(np.array([0, 2, 3], np.uint64), np.array([5, 2**31 - 1, 7], np.int32))
+    dtop = dev(top, 0)
+    with pytest.raises(sdr_amd.SdrbError):
+        gpu_elems(OR, dtop, da, algo="lanemerge")
+    assert_elems_equal(gpu_elems(OR, dtop, da), oracle.port().elem_op(OR, top, a))
