@@ -73,6 +73,7 @@ extern "C" {
 #define SDRB_FLAG_FORCE_RANK 128u    /* element fill: fail with UNSUPPORTED unless the wave-per-pair rank-table kernel applies */
 #define SDRB_FLAG_FORCE_BITMAP 256u   /* element fill: fail with UNSUPPORTED unless the dense-bitset fill applies */
 #define SDRB_FLAG_FORCE_LANEMERGE 512u /* element fill: fail with UNSUPPORTED unless the lane-per-pair merge fill (unions of short rows, ids only) applies */
+#define SDRB_FLAG_FORCE_LANERANK 1024u /* element fill: fail with UNSUPPORTED unless the lane-per-pair rank fill (unions of short rows, ids only, width <= 4096) applies */
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;

@@ -16,7 +16,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (DATA_ARITH, DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITMAP, FLAG_FORCE_LANEMERGE, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_FORCE_RANK, FLAG_FORCE_ROWTABLE, FLAG_ROWWISE, FLAG_SWAP,
+from ._lib import (DATA_ARITH, DATA_EMPTY, DATA_UNIT, FLAG_FORCE_BITMAP, FLAG_FORCE_LANEMERGE, FLAG_FORCE_LANERANK, FLAG_FORCE_BITSLICE, FLAG_FORCE_MERGE, FLAG_FORCE_MFMA, FLAG_FORCE_POPCOUNT, FLAG_FORCE_RANK, FLAG_FORCE_ROWTABLE, FLAG_ROWWISE, FLAG_SWAP,
                    OP_AND, OP_OR, OP_RM, OP_XOR, check)
 
 _KINDS = {"empty": DATA_EMPTY, "unit": DATA_UNIT, "arith": DATA_ARITH, DATA_EMPTY: DATA_EMPTY, DATA_UNIT: DATA_UNIT,
@@ -260,8 +260,11 @@ class SDRBatch:
             f |= FLAG_FORCE_BITMAP
         elif algo == "lanemerge":   # element fill by the lane-per-pair merge kernel
             f |= FLAG_FORCE_LANEMERGE
+        elif algo == "lanerank":    # element fill by the lane-per-pair rank kernel
+            f |= FLAG_FORCE_LANERANK
         elif algo is not None:
-            raise ValueError("algo must be None, 'merge', 'bitslice', 'popcount', 'rowtable', 'rank', 'bitmap' or 'lanemerge'")
+            raise ValueError("algo must be None, 'merge', 'bitslice', 'popcount', 'rowtable', 'rank', 'bitmap', "
+                             "'lanemerge' or 'lanerank'")
         return f
 
     def _size_op(self, op: int, other: "SDRBatch", swap: bool, out, stream, algo):

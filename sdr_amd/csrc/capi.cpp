@@ -1132,21 +1132,24 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         }
         return launch_elem_rank(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }
-    if (flags & (SDRB_FLAG_FORCE_BITMAP | SDRB_FLAG_FORCE_LANEMERGE)) {
-        const bool bitmap = (flags & SDRB_FLAG_FORCE_BITMAP) != 0;
+    if (flags & (SDRB_FLAG_FORCE_BITMAP | SDRB_FLAG_FORCE_LANEMERGE | SDRB_FLAG_FORCE_LANERANK)) {
+        const bool bitmap = (flags & SDRB_FLAG_FORCE_BITMAP) != 0, lanerank = (flags & SDRB_FLAG_FORCE_LANERANK) != 0;
         if (rowwise || a->id_bits != 32 ||
-            !(bitmap ? elem_bitmap_applicable(a, b, swap) : elem_lanemerge_applicable(a, b, op, swap))) {
+            !(bitmap ? elem_bitmap_applicable(a, b, swap)
+                     : lanerank ? elem_lanerank_applicable(a, b, op, swap) : elem_lanemerge_applicable(a, b, op, swap))) {
             set_error("the requested element fill kernel does not apply to these batches / this op");
             return SDRB_ERR_UNSUPPORTED;
         }
-        return bitmap ? launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s)
-                      : launch_elem_lanemerge(a, b, op, swap, out_offsets, out_ids, s);
+        if (bitmap) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
+        if (lanerank) return launch_elem_lanerank(a, b, op, swap, out_offsets, out_ids, s);
+        return launch_elem_lanemerge(a, b, op, swap, out_offsets, out_ids, s);
     }
     if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32) {
         // intersections are small: visiting only the matches (mask table) beats enumerating whole bitsets
         if (op == SDRB_OP_AND && !(flags & SDRB_FLAG_FORCE_ROWTABLE) && mask_table_applicable(a, b))
             return launch_elem_mask_table(a, b, swap, out_offsets, out_ids, out_data, s);
         // unions of short rows, ids only: a lane per pair, coalesced runs out of an LDS stage
+        if (elem_lanerank_applicable(a, b, op, swap)) return launch_elem_lanerank(a, b, op, swap, out_offsets, out_ids, s);
         if (elem_lanemerge_applicable(a, b, op, swap)) return launch_elem_lanemerge(a, b, op, swap, out_offsets, out_ids, s);
         if (elem_bitmap_applicable(a, b, swap)) return launch_elem_bitmap(a, b, op, swap, out_offsets, out_ids, s);
         if (unit_table_fill_applicable(a, b, op, swap))

@@ -219,7 +219,6 @@ __global__ __launch_bounds__(kLmBlock) void k_elem_lanemerge(
             const uint32_t run_len = run_end - run_beg;
             const uint32_t span = shift + run_len, quads_out = (span + 3) / 4;
             int32_t* dst = out_ids + (run_beg - shift);    // 16-byte aligned when out_ids is
-#pragma unroll 2
             for (uint32_t c = lane; c < quads_out; c += 64) {
                 lm_i32x4 v;
                 if constexpr (sizeof(T) == 2) {

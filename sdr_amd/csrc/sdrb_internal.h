@@ -149,6 +149,12 @@ bool elem_lanemerge_applicable(const sdrb_batch* a, const sdrb_batch* b, int op,
 int launch_elem_lanemerge(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
                           int32_t* out_ids, hipStream_t stream);
 
+// elem_lanerank.hip ----------------------------------------------------------------
+// the same results for a declared width <= 4096 and rows <= 64 ids: a lane per pair, places from rank tables
+bool elem_lanerank_applicable(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap);
+int launch_elem_lanerank(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
+                         int32_t* out_ids, hipStream_t stream);
+
 // elem_rank.hip --------------------------------------------------------------------
 // Wave-per-pair fill from rank tables (bitset + popcount prefix per row): any payload kinds, all four
 // ops, declared width <= 32768.

@@ -243,22 +243,26 @@ def test_bitset_element_kernel_vs_oracle(width, max_len, au):
         assert_elems_equal(gpu_elems(op, dt, da), want)
         assert_elems_equal(gpu_elems(op, dt, da, algo="merge"), want)
         assert_elems_equal(gpu_elems(op, dt, da, algo="bitmap"), want)
-        if op != AND:   # unions of short rows: a lane per pair (rows of 100 ids do not fit its LDS stage)
-            try:
-                got = gpu_elems(op, dt, da, algo="lanemerge")
-            except sdr_amd.SdrbError as e:
-                assert e.code == -5 and max_len > 64
-            else:
-                assert max_len <= 64
-                assert_elems_equal(got, want)
+        if op != AND:   # unions of short rows: a lane per pair (rows of 100 ids do not fit the LDS stage)
+            for algo in ("lanemerge", "lanerank"):
+                try:
+                    got = gpu_elems(op, dt, da, algo=algo)
+                except sdr_amd.SdrbError as e:
+                    assert e.code == -5 and max_len > 64
+                else:
+                    assert max_len <= 64
+                    assert_elems_equal(got, want)
     # swapped roles: this = rows of the second batch
     b2 = Batch(*util.ragged_rows(rng, 300, width, max_len))
     db2 = dev(b2, width)
     for op in range(4):
-        off, ids, data = gpu_elems(op, dt, db2, swap=True)
         w_off, w_ids, w_data = oracle.port().elem_op(op, b2, t)
-        assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, b2.n),
-                              util.pair_digests(w_off, w_ids, w_data).reshape(b2.n, t.n).T)
+        for algo in (None, "lanerank", "lanemerge"):
+            if algo is not None and (op == AND or max_len > 64):
+                continue
+            off, ids, data = gpu_elems(op, dt, db2, swap=True, algo=algo)
+            assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, b2.n),
+                                  util.pair_digests(w_off, w_ids, w_data).reshape(b2.n, t.n).T), (op, algo)
 
 
 def test_bitset_element_kernel_not_used_when_a_exceeds_width():

@@ -66,7 +66,7 @@ def test_random_shapes_all_kernels_vs_oracle(seed):
             dig_want = util.pair_digests(w_off, w_ids, w_data).reshape(this.n, arg.n)
             if swap:
                 lens_want, dig_want = lens_want.T, dig_want.T
-            for algo in (None, "merge", "rank", "rowtable", "bitmap", "lanemerge"):
+            for algo in (None, "merge", "rank", "rowtable", "bitmap", "lanemerge", "lanerank"):
                 res = try_algo(lambda algo: getattr(dt, ELEM[op])(da, swap=swap, algo=algo), algo)
                 if res is None:
                     continue
