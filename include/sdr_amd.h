@@ -289,6 +289,20 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
                       void* stream);
 
 /*
+ * The same element operations in ONE call that never waits for the GPU: count, scan and fill are enqueued back to
+ * back on `stream`.  The caller sizes out_ids (and out_data) from the shapes alone: `capacity` elements, at least
+ * sdrb_elem_op_bound() -- |A_i| + |B_j| per pair for ore / xore, |this| for rme, min(|A_i|, |B_j|) for ande --
+ * which for unions of sparse rows is within a few percent of the exact total.  out_offsets[na*nb + 1] receives
+ * the exclusive offsets as above; the exact number of elements is out_offsets[pairs] and, as 64 bits, *total_dev
+ * (device memory, may be NULL), readable once the stream has passed the call.  A call whose bound exceeds 2^32-1
+ * elements is refused (SDRB_ERR_OVERFLOW): use the two-call protocol, which applies the limit to the exact total.
+ * 32-bit ids.
+ */
+int sdrb_elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint64_t* bound);
+int sdrb_elem_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out_offsets,
+                 int32_t* out_ids, float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream);
+
+/*
  * Batched visitors: what the reference's extension API hands to its callbacks (README.md:133-155), for
  * every pair, as arrays -- the raw material for operations the library does not have.
  *   SDRB_VISIT_AND -> andv (SDR.hpp:186-194, 958-997): one record per id match, ascending by id:

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "sdrb_inner": (C.c_int, [_vp, _vp, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_allpairs_topk": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int64, C.c_uint, _vp, _vp, _vp]),
     "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
+    "sdrb_elem_op_bound": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _u64p]),
+    "sdrb_elem_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "sdrb_equal": (C.c_int, [_vp, _vp, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_visit_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
     "sdrb_visit_fill": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),

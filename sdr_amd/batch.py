@@ -55,16 +55,36 @@ def rows_to_csr(rows: Iterable, with_data: bool):
             np.asarray(data, dtype=np.float32) if with_data else None)
 
 
-@dataclass
 class ElemResult:
     """CSR result of an element op over all pairs: pair (i, j) owns
-    ``ids[offsets[i*nb+j] : offsets[i*nb+j+1]]`` (and ``data`` likewise, UnitData only)."""
-    na: int
-    nb: int
-    offsets: "object"            # torch.int32 [na*nb + 1] (values are uint32)
-    ids: "object"                # torch.int32 [total]
-    data: Optional["object"]     # torch.float32 [total] or None
-    total: int
+    ``ids[offsets[i*nb+j] : offsets[i*nb+j+1]]`` (and ``data`` likewise, results with payloads only).
+
+    A result made by the single-call path has buffers sized by an upper bound and its element count still on the
+    device: ``total``, ``ids`` and ``data`` read that count (one stream synchronisation) the first time they are
+    asked for; ``offsets`` and the untrimmed ``ids_buffer`` / ``data_buffer`` never wait."""
+
+    def __init__(self, na, nb, offsets, ids, data, total=None, total_dev=None):
+        self.na = na
+        self.nb = nb
+        self.offsets = offsets            # torch.int32 [na*nb + 1] (values are uint32)
+        self.ids_buffer = ids             # torch.int32 / int64 [>= total]
+        self.data_buffer = data           # torch.float32 [>= total] or None
+        self._total = total
+        self._total_dev = total_dev       # torch.int64 [1] on the device, or None
+
+    @property
+    def total(self) -> int:
+        if self._total is None:
+            self._total = int(self._total_dev.item())
+        return self._total
+
+    @property
+    def ids(self):
+        return self.ids_buffer[: self.total]
+
+    @property
+    def data(self):
+        return None if self.data_buffer is None else self.data_buffer[: self.total]
 
     def to_host(self):
         off = self.offsets.cpu().numpy().view(np.uint32).astype(np.uint64)
@@ -319,7 +339,7 @@ class SDRBatch:
         check(self._lib.sdrb_range_elems_fill(self._h, lo.size, lo.ctypes.data, hi.ctypes.data, offsets.data_ptr(),
                                               ids_buf.data_ptr(),
                                               data_buf.data_ptr() if data_buf is not None else None, s))
-        return ElemResult(lo.size, self.n_rows, offsets, ids_buf[:n], data_buf[:n] if data_buf is not None else None, n)
+        return ElemResult(lo.size, self.n_rows, offsets, ids_buf, data_buf, n)
 
     def point_query(self, ids, *, stream=None):
         """``out[q, j]`` = position of ``ids[q]`` in row j or -1: the batched ``ande(id)``
@@ -378,6 +398,8 @@ class SDRBatch:
         return self._size_op(OP_RM, other, swap, out, stream, algo)
 
     # -- element ops (SDR.hpp:151-152, 209-212, 237-240, 292-293) ---------------------
+    SINGLE_CALL_BYTES = 24 << 30    # largest bound-sized result buffer the single-call path allocates
+
     def _elem_op(self, op: int, other: "SDRBatch", swap: bool, stream, algo, rowwise: bool = False) -> ElemResult:
         torch = _torch()
         dev = f"cuda:{other.device}"
@@ -388,20 +410,33 @@ class SDRBatch:
         offsets = torch.empty(pairs + 1, dtype=torch.int32, device=dev)
         total = C.c_uint64()
         flags = self._flags(swap, algo, rowwise)
+        this_kind = other.data_kind if swap else self.data_kind
+        if op != OP_AND and self.id_bits == 32 and other.id_bits == 32 and pairs:
+            # Unions and differences: the shapes bound the result tightly (|A_i| + |B_j| per pair), so the buffers
+            # are sized by the bound and count, scan and fill are enqueued in one call, with no wait in between.
+            bound = C.c_uint64()
+            check(self._lib.sdrb_elem_op_bound(self._h, other._h, op, flags, C.byref(bound)))
+            cap = int(bound.value)
+            if 0 < cap <= 0xFFFFFFFF and cap * (8 if this_kind != DATA_EMPTY else 4) <= self.SINGLE_CALL_BYTES:
+                ids_buf = torch.empty(cap, dtype=torch.int32, device=dev)
+                data_buf = torch.empty(cap, dtype=torch.float32, device=dev) if this_kind != DATA_EMPTY else None
+                total_dev = torch.empty(1, dtype=torch.int64, device=dev)
+                check(self._lib.sdrb_elem_op(self._h, other._h, op, flags, offsets.data_ptr(), ids_buf.data_ptr(),
+                                             data_buf.data_ptr() if data_buf is not None else None, cap,
+                                             total_dev.data_ptr(), s))
+                return ElemResult(1 if rowwise else self.n_rows, other.n_rows, offsets, ids_buf, data_buf,
+                                  total_dev=total_dev)
         check(self._lib.sdrb_elem_op_count(self._h, other._h, op, flags, offsets.data_ptr(),
                                            C.byref(total), s))
         n = int(total.value)
         # buffers keep at least one element so an empty result still has a valid pointer
         ids_buf = torch.empty(max(n, 1), dtype=torch.int64 if self.id_bits == 64 else torch.int32, device=dev)
-        this_kind = other.data_kind if swap else self.data_kind
         data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if this_kind != DATA_EMPTY else None
         fill = self._lib.sdrb_elem_op_fill64 if self.id_bits == 64 else self._lib.sdrb_elem_op_fill
         check(fill(self._h, other._h, op, flags, offsets.data_ptr(),
                                           ids_buf.data_ptr(),
                                           data_buf.data_ptr() if data_buf is not None else None, s))
-        ids = ids_buf[:n]
-        data = data_buf[:n] if data_buf is not None else None
-        return ElemResult(1 if rowwise else self.n_rows, other.n_rows, offsets, ids, data, n)
+        return ElemResult(1 if rowwise else self.n_rows, other.n_rows, offsets, ids_buf, data_buf, n)
 
     # -- row-wise evaluation and the in-place ops ------------------------------------------------
     def rowwise_size(self, name: str, other: "SDRBatch", *, swap=False, stream=None):

@@ -873,13 +873,9 @@ int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
 }
 
 namespace {
-// counts[0..pairs) -> exclusive offsets[0..pairs] in place, the exact total to the host (synchronises);
-// a result of 2^32 elements or more cannot be addressed by the 32-bit offsets
-int finish_count(int device, uint32_t* out_offsets, uint64_t pairs, uint64_t* total, hipStream_t s) {
-    unsigned long long* total_dev = static_cast<unsigned long long*>(sdrb::workspace(device, s, 10, sizeof(unsigned long long)));
-    if (!total_dev) return SDRB_ERR_HIP;
-    const int rc = sdrb::launch_exclusive_scan_u32(device, out_offsets, pairs + 1, pairs, total_dev, s);
-    if (rc != SDRB_OK) return rc;
+// the exact total to the host (synchronises); a result of 2^32 elements or more cannot be addressed by the
+// 32-bit offsets
+int read_total(const unsigned long long* total_dev, uint64_t* total, hipStream_t s) {
     unsigned long long t64 = 0;
     SDRB_HIP(hipMemcpyAsync(&t64, total_dev, sizeof t64, hipMemcpyDeviceToHost, s));
     SDRB_HIP(hipStreamSynchronize(s));
@@ -889,6 +885,16 @@ int finish_count(int device, uint32_t* out_offsets, uint64_t pairs, uint64_t* to
     }
     *total = t64;
     return SDRB_OK;
+}
+
+// counts[0..pairs) -> exclusive offsets[0..pairs] in place, then read_total
+int finish_count(int device, uint32_t* out_offsets, uint64_t pairs, uint64_t* total, hipStream_t s) {
+    unsigned long long* total_dev = static_cast<unsigned long long*>(sdrb::workspace(device, s, 10, sizeof(unsigned long long)));
+    if (!total_dev) return SDRB_ERR_HIP;
+    // sizes at out_offsets[0..pairs) -> exclusive offsets [0..pairs], the 64-bit total to total_dev
+    const int rc = sdrb::launch_exclusive_scan_u32(device, out_offsets, pairs + 1, pairs, total_dev, s);
+    if (rc != SDRB_OK) return rc;
+    return read_total(total_dev, total, s);
 }
 
 int check_queries(const sdrb_batch* b, uint64_t n, const int32_t* lo, const int32_t* hi, bool ranges) {
@@ -1036,13 +1042,15 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
     return launch_allpairs_bitslice(a, b, k, exclude_offset, out_counts, out_rows, s);
 }
 
-int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
-                       uint32_t* out_offsets, uint64_t* total, void* stream) {
+namespace {
+// checks shared by the counting entry points; *pairs = number of results
+int check_count_call(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, const void* out_offsets,
+                     uint64_t* pairs) {
     int rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
     if (rc != SDRB_OK) return rc;
-    if (!out_offsets || !total) {
-        set_error("sdrb_elem_op_count: null output");
+    if (!out_offsets) {
+        set_error("element op: out_offsets is null");
         return SDRB_ERR_INVALID_ARG;
     }
     const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
@@ -1051,16 +1059,38 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
                   (unsigned long long)a->n_rows, (unsigned long long)b->n_rows);
         return SDRB_ERR_INVALID_ARG;
     }
-    const uint64_t pairs = rowwise ? b->n_rows : a->n_rows * b->n_rows;
-    if (pairs >= 0xFFFFFFFFull) {
-        set_error("too many pairs for one call (%llu)", (unsigned long long)pairs);
+    *pairs = rowwise ? b->n_rows : a->n_rows * b->n_rows;
+    if (*pairs >= 0xFFFFFFFFull) {
+        set_error("too many pairs for one call (%llu)", (unsigned long long)*pairs);
         return SDRB_ERR_OVERFLOW;
     }
-    // the scan carries sums in 62 bits: no result can come near that (every element is output at most
+    // the scan carries sums in 64 bits; no result can come near that (every element is output at most
     // once per row of the other batch)
     if ((unsigned __int128)a->nnz * b->n_rows + (unsigned __int128)b->nnz * a->n_rows >= ((unsigned __int128)1 << 61)) {
         set_error("result far beyond 2^32-1 elements; split the A batch");
         return SDRB_ERR_OVERFLOW;
+    }
+    return SDRB_OK;
+}
+
+// the most elements the result of `op` can hold, from the batches' shapes alone
+uint64_t elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags) {
+    const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0, swap = (flags & SDRB_FLAG_SWAP) != 0;
+    const uint64_t from_a = rowwise ? a->nnz : a->nnz * b->n_rows, from_b = rowwise ? b->nnz : b->nnz * a->n_rows;
+    if (op == SDRB_OP_AND) return from_a < from_b ? from_a : from_b;
+    if (op == SDRB_OP_RM) return swap ? from_b : from_a;
+    return from_a + from_b;
+}
+}  // namespace
+
+int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
+                       uint32_t* out_offsets, uint64_t* total, void* stream) {
+    uint64_t pairs = 0;
+    int rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
+    if (rc != SDRB_OK) return rc;
+    if (!total) {
+        set_error("sdrb_elem_op_count: null output");
+        return SDRB_ERR_INVALID_ARG;
     }
     DeviceGuard guard(b->device);
     if (!guard.ok) {
@@ -1074,6 +1104,17 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
         if (rc != SDRB_OK) return rc;
     }
     return finish_count(b->device, out_offsets, pairs, total, s);
+}
+
+int sdrb_elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint64_t* bound) {
+    int rc = check_pair(a, b, op);
+    if (rc != SDRB_OK) return rc;
+    if (!bound) {
+        set_error("sdrb_elem_op_bound: null output");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    *bound = elem_op_bound(a, b, op, flags);
+    return SDRB_OK;
 }
 
 namespace {
@@ -1168,6 +1209,40 @@ int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned
 int sdrb_elem_op_fill64(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                         const uint32_t* out_offsets, int64_t* out_ids, float* out_data, void* stream) {
     return elem_op_fill_any(a, b, op, flags, out_offsets, out_ids, 64, out_data, stream);
+}
+
+int sdrb_elem_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out_offsets,
+                 int32_t* out_ids, float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream) {
+    uint64_t pairs = 0;
+    int rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
+    if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_elem_op");
+    if (rc != SDRB_OK) return rc;
+    const uint64_t bound = elem_op_bound(a, b, op, flags);
+    if (bound > 0xFFFFFFFFull) {
+        set_error("the result may hold up to %llu elements, more than 32-bit offsets address: use "
+                  "sdrb_elem_op_count / sdrb_elem_op_fill (which apply the limit to the exact total) or split A",
+                  (unsigned long long)bound);
+        return SDRB_ERR_OVERFLOW;
+    }
+    if (capacity < bound) {
+        set_error("sdrb_elem_op: capacity %llu is below the bound of this call (%llu elements, see sdrb_elem_op_bound)",
+                  (unsigned long long)capacity, (unsigned long long)bound);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pairs) {
+        rc = sdrb_size_op(a, b, op, flags & (SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE | SDRB_FLAG_FORCE_ROWTABLE), out_offsets,
+                          b->n_rows, stream);
+        if (rc != SDRB_OK) return rc;
+    }
+    rc = launch_exclusive_scan_u32(b->device, out_offsets, pairs + 1, pairs, reinterpret_cast<unsigned long long*>(total_dev), s);
+    if (rc != SDRB_OK || pairs == 0 || bound == 0) return rc;
+    return sdrb_elem_op_fill(a, b, op, flags, out_offsets, out_ids, out_data, stream);
 }
 
 namespace {
