@@ -53,10 +53,16 @@ def cpu_baseline(nq: int, nd: int, threads: int):
         assert chk == chk1
     else:
         sec = sec1
+    # BASELINE.json configs[0] itself: ONE query against 10 000 rows, one thread
+    q1 = oracle.Batch(*sdr_amd.synth_csr(2, 0, 1, WIDTH, ACTIVE))
+    d1 = oracle.Batch(*sdr_amd.synth_csr(1, 0, 10_000, WIDTH, ACTIVE))
+    sec_c1, _ = impl.time_size_op(oracle.AND, q1, d1, repeats=5, threads=1)
     return {
         "value": nq * nd / sec, "unit": "pair-ops/s", "cores": threads, "kind": kind,
         "sample": f"ands, {nq} queries x {nd} rows, width {WIDTH}/{ACTIVE} active, std::vector rows, "
-                  f"g++ -O2, best of 3; single thread: {one_thread:.3e} pair-ops/s",
+                  f"g++ -O2, best of 3; single thread: {one_thread:.3e} pair-ops/s; the reference's own case "
+                  f"(1 query x 10000 rows, one thread, best of 5): {10_000 / sec_c1:.3e} pair-ops/s -- the rate does "
+                  f"not depend on the sample size once the rows fit the caches",
     }
 
 
@@ -71,6 +77,8 @@ def main() -> None:
     ap.add_argument("--algo", default=None, choices=[None, "merge", "bitslice", "popcount"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other BASELINE.json configs reported beside the metric (element ops, UnitData, all-pairs)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="initialise RCCL and broadcast the queries every step even with one rank")
     args = ap.parse_args()
@@ -201,6 +209,13 @@ def main() -> None:
         if world == 1 and args.op == "ands" and nq > 1:
             n0 = int(q_off[1])
             line["one_query"] = one_query_regime(engine.pack_host(q_off[:2], q_ids[:n0], None, WIDTH), db.shard, nd, dev)
+        if world == 1 and not args.no_secondary and args.op == "ands":
+            # the other configs of BASELINE.json, one GPU's share each, outside the timed region and never
+            # part of `value`; the 17 GB of counts are released first
+            del out
+            state.clear()
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(64, 100_000, threads)
@@ -230,6 +245,140 @@ def one_query_regime(q1, shard, nd: int, dev) -> dict:
     ach = nbytes / (ms * 1e-3) / 1e9
     return {"workload": f"ands: 1 query x {nd} rows", "value": nd / (ms * 1e-3), "unit": "pair-ops/s",
             "ms": ms, "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+
+
+I8_PEAK_OPS = 5.03e15   # dense int8 MFMA: 256 CUs x 4 SIMDs x 2048 ops/clk x 2.4 GHz
+
+
+def _timed(fn, reps=5):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    best, res = 1e30, None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        res = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best, res
+
+
+def _elem_parity(res, counts, op, q_csr, d_csr, nd, sample_rows, with_data):
+    """Result lengths equal the size op's counts for EVERY pair, and the elements (ids, payload bits) of every
+    query against a sample of rows equal the oracle's."""
+    import oracle
+    import torch
+    nq = res.na
+    off = res.offsets
+    lens = (off[1:] - off[:-1]).view(nq, nd)
+    ok = bool(torch.equal(lens, counts[:nq, :nd]))
+    q = oracle.Batch(*q_csr)
+    d_off, d_ids, d_data = d_csr
+    s_off, s_ids, _ = _gather_rows(d_off, d_ids, sample_rows)
+    s_data = np.concatenate([d_data[int(d_off[r]):int(d_off[r + 1])] for r in sample_rows]) if with_data else None
+    w_off, w_ids, w_data = oracle.port().elem_op(op, q, oracle.Batch(s_off, s_ids, s_data))
+    pair = torch.as_tensor(np.add.outer(np.arange(nq) * nd, sample_rows).reshape(-1), device=off.device)
+    lo = off[pair].cpu().numpy().view(np.uint32).astype(np.int64)
+    hi = off[pair + 1].cpu().numpy().view(np.uint32).astype(np.int64)
+    ids_host = [res.ids_buffer[a:b].cpu().numpy() for a, b in zip(lo, hi)]
+    got_ids = np.concatenate(ids_host) if ids_host else np.zeros(0, np.int32)
+    ok = ok and np.array_equal(hi - lo, np.diff(w_off).astype(np.int64)) and np.array_equal(got_ids, w_ids)
+    if with_data and ok:
+        got_data = np.concatenate([res.data_buffer[a:b].cpu().numpy() for a, b in zip(lo, hi)])
+        ok = np.array_equal(got_data.view(np.uint32), w_data.view(np.uint32))
+    return bool(ok)
+
+
+def secondary_configs(dev) -> dict:
+    """BASELINE.json configs 3, 4 and 5 on one GPU: time through the API (count, host read of the total,
+    allocation and fill for the element ops), algorithmic bytes = every input once + every output once, the
+    fraction of the 8 TB/s peak they amount to (int8 operations against the matrix-core peak for the dense
+    all-pairs kernel), and a parity bit from the oracle."""
+    import torch
+
+    import oracle
+    import sdr_amd
+    from sdr_amd import SDRBatch
+    out = {}
+    rng = np.random.default_rng(7)
+
+    def line(ms, nbytes, parity, **extra):
+        ach = nbytes / (ms * 1e-3) / 1e9
+        return dict(ms=ms, algorithmic_bytes=int(nbytes), achieved_GBps=ach, frac=ach / HBM_PEAK_GBS, parity=parity, **extra)
+
+    # config 3: element ops with variable-length outputs over 1 Mi rows, EmptyData 2048/40
+    nd = 1 << 20
+    d_csr = sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE)
+    d = SDRBatch.from_csr(*d_csr, width=WIDTH)
+    sample = np.sort(rng.choice(nd, 48, replace=False))
+    for nq in (1, 16):
+        q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE)
+        q = SDRBatch.from_csr(*q_csr, width=WIDTH)
+        in_bytes = (nd + nq) * (4 * ACTIVE + 4)
+        for name, size_name, op in (("ande", "ands", oracle.AND), ("ore", "ors", oracle.OR)):
+            ms, res = _timed(lambda: getattr(q, name)(d))
+            counts = getattr(q, size_name)(d)
+            nbytes = in_bytes + (nq * nd + 1) * 4 + res.total * 4
+            out[f"c3_{name}_q{nq}"] = line(ms, nbytes, _elem_parity(res, counts, op, q_csr, d_csr, nd, sample, False),
+                                           workload=f"{name}: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData",
+                                           elements=res.total)
+            del res, counts
+    del d
+    torch.cuda.empty_cache()
+
+    # config 4: UnitData 16384 / 328 active, one GPU's 128 Ki rows of the 1 Mi-row database, 64 queries
+    w4, a4, nq4, nd4 = 16384, 328, 64, 1 << 17
+    d_csr = sdr_amd.synth_csr(1, 0, nd4, w4, a4, True)
+    q_csr = sdr_amd.synth_csr(2, 0, nq4, w4, a4, True)
+    d = SDRBatch.from_csr(*d_csr, width=w4)
+    q = SDRBatch.from_csr(*q_csr, width=w4)
+    in_bytes = (nd4 + nq4) * (8 * a4 + 4)
+    ms_s, counts = _timed(lambda: q.ands(d))
+    sample = np.sort(rng.choice(nd4, 16, replace=False))
+    want = oracle.port().size_op(oracle.AND, oracle.Batch(*q_csr),
+                                 oracle.Batch(*_gather_rows(d_csr[0], d_csr[1], sample)[:2],
+                                              np.concatenate([d_csr[2][int(d_csr[0][r]):int(d_csr[0][r + 1])] for r in sample])))
+    got = counts[:, torch.as_tensor(sample, device=dev)].cpu().numpy().view(np.uint32)
+    out["c4_ands"] = line(ms_s, in_bytes + nq4 * nd4 * 4, bool(np.array_equal(got, want)),
+                          workload=f"ands: {nq4} x {nd4} rows, width {w4}/{a4}, UnitData (multiply + relevance filter)")
+    ms_e, res = _timed(lambda: q.ande(d))
+    out["c4_ande"] = line(ms_e, in_bytes + (nq4 * nd4 + 1) * 4 + res.total * 8,
+                          _elem_parity(res, counts, oracle.AND, q_csr, d_csr, nd4, sample, True),
+                          workload=f"ande: {nq4} x {nd4} rows, width {w4}/{a4}, UnitData", elements=res.total)
+    del res, counts, d, q
+    torch.cuda.empty_cache()
+
+    # config 5: all-pairs overlap + top-16, one GPU's 32 Ki rows against all 256 Ki rows, both kernels
+    na5, nb5, k5 = 1 << 15, 1 << 18, 16
+    off, ids, _ = sdr_amd.synth_csr(1, 0, nb5, WIDTH, ACTIVE)
+    b = SDRBatch.from_csr(off, ids, None, width=WIDTH)
+    a = SDRBatch.from_csr(off[: na5 + 1].copy(), ids[: int(off[na5])], None, width=WIDTH)
+    pick = np.linspace(0, na5 - 1, 4).astype(np.int64)
+    want = oracle.port().size_op(oracle.AND, oracle.Batch(*_gather_rows(off, ids, pick)), oracle.Batch(off, ids, None))
+    results = {}
+    for algo in ("bitslice", "mfma"):
+        ms, (cnt, rows) = _timed(lambda: a.allpairs_topk(b, k5, exclude_offset=0, algo=algo), reps=3)
+        gc, gr = cnt.cpu().numpy(), rows.cpu().numpy()
+        results[algo] = (gc, gr)
+        ok = True
+        for n, i in enumerate(pick):
+            c = want[n].astype(np.int64)
+            cand = np.arange(nb5)
+            cand = cand[cand != i]
+            order = cand[np.lexsort((cand, -c[cand]))][:k5]
+            ok = ok and np.array_equal(gr[i], order) and np.array_equal(gc[i], c[order])
+        ops = 2.0 * na5 * nb5 * WIDTH
+        entry = dict(ms=ms, pair_ops_per_s=na5 * nb5 / (ms * 1e-3), parity=bool(ok),
+                     workload=f"all-pairs overlap + top-{k5}: {na5} x {nb5} rows, width {WIDTH}/{ACTIVE}, self excluded")
+        if algo == "mfma":
+            entry.update(int8_ops_per_s=ops / (ms * 1e-3), peak_int8_ops_per_s=I8_PEAK_OPS, frac=ops / (ms * 1e-3) / I8_PEAK_OPS)
+        out[f"c5_allpairs_{algo}"] = entry
+    same = np.array_equal(results["bitslice"][0], results["mfma"][0]) and np.array_equal(results["bitslice"][1], results["mfma"][1])
+    out["c5_allpairs_bitslice"]["parity"] = out["c5_allpairs_bitslice"]["parity"] and bool(same)
+    out["c5_allpairs_mfma"]["parity"] = out["c5_allpairs_mfma"]["parity"] and bool(same)
+    return out
 
 
 def _gather_rows(off, ids, rows):

@@ -57,6 +57,8 @@ def main():
         d = SDRBatch.from_csr(*sdr_amd.synth_csr(1, 0, nd, width, active, unit), width=width)
         eb = 8 if unit else 4
         in_bytes = nd * (eb * active + 4) + nq * (eb * active + 4)
+        # ors never looks at payloads (SDR.hpp:1298-1301): its kernel reads the ids only
+        in_bytes_ids = nd * (4 * active + 4) + nq * (4 * active + 4)
         for sname, ename in (("ands", "ande"), ("ors", "ore"), ("xors", "xore"), ("rms", "rme")):
             if only and sname not in only:
                 continue
@@ -65,14 +67,14 @@ def main():
                 ms_e, res = timed(lambda: getattr(q, ename)(d, algo=args.algo), args.reps)
             except sdr_amd.SdrbError as e:      # e.g. a union too large for 32-bit offsets: size op only
                 print(json.dumps({"case": tag, "queries": nq, "rows": nd, "size_op": sname, "size_ms": round(ms_s, 4),
-                                  "size_GBps": round((in_bytes + nq * nd * 4) / ms_s / 1e6, 1),
+                                  "size_GBps": round(((in_bytes_ids if sname == "ors" else in_bytes) + nq * nd * 4) / ms_s / 1e6, 1),
                                   "elem_op": ename, "skipped": str(e)[:80]}), flush=True)
                 continue
-            out_bytes = nq * nd * 4 + res.total * eb
+            out_bytes = (nq * nd + 1) * 4 + res.total * eb
             print(json.dumps({
                 "case": tag, "queries": nq, "rows": nd, "width": width, "active": active, "unit": unit,
                 "size_op": sname, "size_ms": round(ms_s, 4),
-                "size_GBps": round((in_bytes + nq * nd * 4) / ms_s / 1e6, 1),
+                "size_GBps": round(((in_bytes_ids if sname == "ors" else in_bytes) + nq * nd * 4) / ms_s / 1e6, 1),
                 "elem_op": ename, "elem_ms": round(ms_e, 4), "elements": res.total,
                 "elem_GBps": round((in_bytes + out_bytes) / ms_e / 1e6, 1),
                 "pair_ops_per_s": round(nq * nd / (ms_e * 1e-3), 0)}), flush=True)
