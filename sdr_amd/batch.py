@@ -93,6 +93,43 @@ class ElemResult:
         return off, ids, data
 
 
+class ChunkedElemResult:
+    """An element-op result too long for one CSR with 32-bit offsets: rows ``starts[c] .. starts[c+1]`` of A
+    are held by ``chunks[c]``, an :class:`ElemResult` over those rows of A and all rows of B."""
+
+    def __init__(self, na, nb, starts, chunks):
+        self.na, self.nb, self.starts, self.chunks = na, nb, list(starts), list(chunks)
+
+    @property
+    def total(self) -> int:
+        return sum(c.total for c in self.chunks)
+
+    def chunk_of(self, i: int):
+        """``(chunk, row of A inside it)`` for row i of A."""
+        for c in range(len(self.chunks)):
+            if self.starts[c] <= i < self.starts[c + 1]:
+                return self.chunks[c], i - self.starts[c]
+        raise IndexError(i)
+
+    def pair(self, i: int, j: int):
+        """Device tensors ``(ids, data)`` of result (i, j)."""
+        chunk, r = self.chunk_of(i)
+        lo, hi = (int(x) & 0xFFFFFFFF for x in chunk.offsets[r * self.nb + j: r * self.nb + j + 2].tolist())
+        return chunk.ids_buffer[lo:hi], None if chunk.data_buffer is None else chunk.data_buffer[lo:hi]
+
+    def to_host(self):
+        """One CSR with 64-bit offsets on the host (only sensible for results that fit host memory)."""
+        offs, ids, data, base = [np.zeros(1, np.uint64)], [], [], 0
+        for c in self.chunks:
+            o, i, d = c.to_host()
+            offs.append(o[1:] + np.uint64(base))
+            ids.append(i)
+            data.append(d)
+            base += int(o[-1])
+        return (np.concatenate(offs), np.concatenate(ids),
+                None if data[0] is None else np.concatenate(data))
+
+
 @dataclass
 class VisitResult:
     """What the reference's visitors are called with, for all pairs: pair (i, j) owns records
@@ -411,6 +448,12 @@ class SDRBatch:
         total = C.c_uint64()
         flags = self._flags(swap, algo, rowwise)
         this_kind = other.data_kind if swap else self.data_kind
+        if not rowwise and self.id_bits == 32 and other.id_bits == 32 and pairs:
+            # more elements than 32-bit offsets address (certainly for unions, possibly for intersections):
+            # the rows of A are cut into chunks whose results fit, one CSR each
+            chunked = self._elem_op_chunked(op, other, swap, stream, algo, flags)
+            if chunked is not None:
+                return chunked
         if op != OP_AND and self.id_bits == 32 and other.id_bits == 32 and pairs:
             # Unions and differences: the shapes bound the result tightly (|A_i| + |B_j| per pair), so the buffers
             # are sized by the bound and count, scan and fill are enqueued in one call, with no wait in between.
@@ -437,6 +480,56 @@ class SDRBatch:
                                           ids_buf.data_ptr(),
                                           data_buf.data_ptr() if data_buf is not None else None, s))
         return ElemResult(1 if rowwise else self.n_rows, other.n_rows, offsets, ids_buf, data_buf, n)
+
+    def _elem_op_chunked(self, op, other, swap, stream, algo, flags):
+        """None when one call can hold the result; else a :class:`ChunkedElemResult`."""
+        bound = C.c_uint64()
+        check(self._lib.sdrb_elem_op_bound(self._h, other._h, op, flags, C.byref(bound)))
+        limit = 0xFFFFFFFF
+        if int(bound.value) <= limit:
+            return None
+        torch = _torch()
+        if op == OP_AND:
+            # the bound of an intersection is loose: the exact total decides
+            sizes = self._size_op(op, other, swap, None, stream, algo if algo in ("merge", "rowtable") else None)
+            per_row = sizes.to(torch.int64).sum(dim=1).cpu().numpy()
+            del sizes
+        else:
+            a_off = self.to_wire(stream=stream)[: self.n_rows + 1].to(torch.int64).cpu().numpy() & 0xFFFFFFFF
+            a_len = np.diff(a_off)
+            if op == OP_RM:
+                per_row = a_len * other.n_rows if not swap else np.full(self.n_rows, other.nnz, dtype=np.int64)
+            else:
+                per_row = a_len * other.n_rows + other.nnz
+        if int(per_row.sum()) <= limit:
+            return None
+        if int(per_row.max(initial=0)) > limit:
+            raise _lib.SdrbError(-6, "one row of A against all rows of B already yields more than 2^32-1 elements: "
+                                     "split B")
+        # greedy chunks of consecutive rows of A
+        starts, acc = [0], 0
+        for i, n in enumerate(per_row.tolist()):
+            if acc + n > limit:
+                starts.append(i)
+                acc = 0
+            acc += n
+        starts.append(self.n_rows)
+        wire = self.to_wire(stream=stream)
+        n, nnz = self.n_rows, self.nnz
+        off_t, ids_t = wire[: n + 1], wire[n + 1: n + 1 + nnz]
+        data_t = wire[n + 1 + nnz:].view(torch.float32) if self.data_kind != DATA_EMPTY else None
+        stats = self.stats()
+        off_host = off_t.to(torch.int64).cpu().numpy() & 0xFFFFFFFF
+        chunks = []
+        for c in range(len(starts) - 1):
+            i0, i1 = starts[c], starts[c + 1]
+            lo, hi = int(off_host[i0]), int(off_host[i1])
+            part = SDRBatch(self.device, self.width, self.data_kind)
+            part.adopt_device((off_t[i0: i1 + 1] - off_t[i0]).contiguous(), ids_t[lo:hi],
+                              data_t[lo:hi] if data_t is not None else None, max_row_len=stats["max_row_len"],
+                              min_id=stats["min_id"], max_id=stats["max_id"])
+            chunks.append(part._elem_op(op, other, swap, stream, algo))
+        return ChunkedElemResult(self.n_rows, other.n_rows, starts, chunks)
 
     # -- row-wise evaluation and the in-place ops ------------------------------------------------
     def rowwise_size(self, name: str, other: "SDRBatch", *, swap=False, stream=None):
