@@ -211,7 +211,9 @@ bool allpairs_bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b, uint
     if (a->width <= 0 || b->width <= 0 || table_width(a, b) > 4096) return false;
     if (a->max_row_len > 64) return false;        // the lane keeps its whole row in registers
     if (k == 0 || k > (uint32_t)LIST) return false;
-    if (a->n_rows > 0x7FFFFF00ull || b->n_rows > 0x7FFFFF00ull) return false;
+    if (a->n_rows > 0x7FFFFF00ull) return false;
+    // the merge holds 32 splits of 16 keys per row, and a split's local row index must fit the key
+    if (b->n_rows > 32ull * (kTopkMaxSplitRows / kTileRows) * kTileRows) return false;   // 16 775 168 candidate rows
     return true;
 }
 

@@ -451,7 +451,9 @@ bool allpairs_mfma_applicable(const sdrb_batch* a, const sdrb_batch* b, uint32_t
     // counts must fit the key: an overlap never exceeds the shorter row
     const uint32_t cap = a->max_row_len < b->max_row_len ? a->max_row_len : b->max_row_len;
     if (cap >= (1u << (31 - kKeyShift))) return false;
-    if (a->n_rows > 0x7FFFFF00ull || b->n_rows > 0x7FFFFF00ull) return false;
+    if (a->n_rows > 0x7FFFFF00ull) return false;
+    // the merge holds 8 splits x 4 lists of 16 keys per row, and a split's local row index must fit the key
+    if (b->n_rows > 8ull * (kMaxSplitRows / kPanel) * kPanel) return false;      // 4 192 256 candidate rows
     return true;
 }
 

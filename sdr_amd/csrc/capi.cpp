@@ -1027,7 +1027,8 @@ int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int
     const bool want_mfma = (flags & SDRB_FLAG_FORCE_MFMA) != 0, want_bitslice = (flags & SDRB_FLAG_FORCE_BITSLICE) != 0;
     if ((want_mfma && !can_mfma) || (want_bitslice && !can_bitslice) || (!can_mfma && !can_bitslice)) {
         set_error("sdrb_allpairs_topk: kernel not applicable (k <= 16 and declared widths needed; bit-sliced: "
-                  "widths <= 4096 and rows of a <= 64 ids; matrix-core: widths <= 16384 and rows shorter than 4096 ids)");
+                  "widths <= 4096, rows of a <= 64 ids, at most 16 775 168 rows of b; matrix-core: widths <= 16384, rows "
+                  "shorter than 4096 ids, at most 4 192 256 rows of b; cut b into row ranges beyond that)");
         return SDRB_ERR_UNSUPPORTED;
     }
     DeviceGuard guard(b->device);

@@ -112,11 +112,24 @@ int map_file(const char* path, Mapping* m) {
     auto section_ok = [&](uint64_t pos, uint64_t count, uint64_t elem) {
         return pos % kAlign == 0 && pos >= sizeof(Header) && pos <= size && count <= (size - pos) / elem;
     };
-    if (h->nnz > 0xFFFFFFFFFFull || !section_ok(h->ids_pos, h->nnz, 4) || !section_ok(h->offsets_pos, h->n_rows + 1, 8) ||
-        (has_data && !section_ok(h->data_pos, h->nnz, 4)) || (!has_data && h->data_pos != 0)) {
+    // n_rows + 1 offsets must fit: compared as n_rows < capacity, so that n_rows = 2^64-1 cannot wrap to zero
+    const bool rows_ok = h->offsets_pos <= size && h->n_rows < (size - h->offsets_pos) / 8;
+    if (h->nnz > 0xFFFFFFFFFFull || !rows_ok || !section_ok(h->ids_pos, h->nnz, 4) ||
+        !section_ok(h->offsets_pos, h->n_rows + 1, 8) || (has_data && !section_ok(h->data_pos, h->nnz, 4)) ||
+        (!has_data && h->data_pos != 0)) {
         set_error("%s: section table is inconsistent with the file size", path);
         return SDRB_ERR_FORMAT;
     }
+    // the sections may come in any order but never share bytes
+    struct Span { uint64_t lo, hi; };
+    Span spans[3] = {{h->ids_pos, h->ids_pos + h->nnz * 4}, {h->offsets_pos, h->offsets_pos + (h->n_rows + 1) * 8},
+                     {has_data ? h->data_pos : 0, has_data ? h->data_pos + h->nnz * 4 : 0}};
+    for (int x = 0; x < 3; ++x)
+        for (int y = x + 1; y < 3; ++y)
+            if (spans[x].lo < spans[y].hi && spans[y].lo < spans[x].hi) {
+                set_error("%s: sections overlap", path);
+                return SDRB_ERR_FORMAT;
+            }
     const char* c = static_cast<const char*>(m->base);
     m->h = h;
     m->ids = reinterpret_cast<const int32_t*>(c + h->ids_pos);
@@ -155,6 +168,7 @@ struct sdrb_file_writer {
     bool arith = false;          // ... of ArithData: any finite value instead of [0,1]
     uint64_t pos = 0;            // write position in the main file
     uint64_t nnz = 0;
+    bool failed = false;         // a write stopped part-way: the file no longer matches `pos`, only abort is left
     std::vector<uint64_t> offsets{0};
 };
 
@@ -207,6 +221,10 @@ static int sdrb_file_writer_append_impl(sdrb_file_writer* w, uint64_t n_rows, co
         set_error("sdrb_file_writer_append: null argument or row_offsets[0] != 0");
         return SDRB_ERR_INVALID_ARG;
     }
+    if (w->failed) {
+        set_error("sdrb_file_writer_append: an earlier write to %s failed; abort the writer", w->path.c_str());
+        return SDRB_ERR_IO;
+    }
     const uint64_t nnz = row_offsets[n_rows];
     if ((nnz && !ids) || (nnz && w->unit && !data)) {
         set_error("sdrb_file_writer_append: element arrays missing");
@@ -241,6 +259,7 @@ static int sdrb_file_writer_append_impl(sdrb_file_writer* w, uint64_t n_rows, co
     if (!write_all(w->fd, ids, nnz * sizeof(int32_t)) ||
         (w->unit && !write_all(w->data_fd, data, nnz * sizeof(float)))) {
         set_error("write to %s failed: %s", w->path.c_str(), std::strerror(errno));
+        w->failed = true;
         return SDRB_ERR_IO;
     }
     w->pos += nnz * sizeof(int32_t);
@@ -255,6 +274,12 @@ int sdrb_file_writer_append(sdrb_file_writer* w, uint64_t n_rows, const uint64_t
 
 static int sdrb_file_writer_close_impl(sdrb_file_writer* w) {
     if (!w) return SDRB_OK;
+    if (w->failed) {
+        const std::string broken = w->path;
+        sdrb_file_writer_abort(w);
+        set_error("%s: an earlier write failed, the file was removed", broken.c_str());
+        return SDRB_ERR_IO;
+    }
     Header h{};
     std::memcpy(h.magic, kMagic, 8);
     h.version = 1;

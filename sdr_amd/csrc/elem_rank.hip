@@ -790,6 +790,13 @@ struct Args {
     hipStream_t stream;
 };
 
+// Dynamic LDS beyond 64 KiB has to be granted per kernel before the launch.
+template <typename K>
+void allow_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 template <int OP, bool SWAP, bool A_UNIT, bool B_UNIT, bool VISIT = false, bool ARITH = false>
 void launch(const Args& g) {
     if (g.runs) {
@@ -806,6 +813,8 @@ void launch(const Args& g) {
     }
     if (g.short_rows) {
         const uint32_t longest = g.a->max_row_len > g.b->max_row_len ? g.a->max_row_len : g.b->max_row_len;
+        allow_lds(&k_elem_rank_short<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 3>, g.lds);
+        allow_lds(&k_elem_rank_short<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 4>, g.lds);
         if (longest <= 48)
             hipLaunchKernelGGL((k_elem_rank_short<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH, 3>), g.grid, dim3(kBlock), g.lds,
                                g.stream, g.a->d_offsets, g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets,
@@ -818,9 +827,7 @@ void launch(const Args& g) {
                                g.rows_per_wave);
         return;
     }
-    if (g.lds > 64 * 1024)   // beyond the default limit of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    allow_lds(&k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>, g.lds);
     hipLaunchKernelGGL((k_elem_rank<OP, SWAP, A_UNIT, B_UNIT, VISIT, ARITH>), g.grid, dim3(kBlock), g.lds, g.stream, g.a->d_offsets,
                        g.a->d_ids, g.a->d_data, (uint32_t)g.a->n_rows, g.a_tab, g.b->d_offsets, g.b->d_ids, g.b->d_data,
                        (uint32_t)g.b->n_rows, g.out_off, g.out_ids, g.out_data, g.nw, g.qc, g.cap_a, g.cap_b, g.rows_per_wave);

@@ -188,10 +188,11 @@ class ShardedDatabase:
             off_t, ids_t, data_t = packed
             return self._pack(off_t, ids_t, data_t, into)
         header = torch.zeros(3, dtype=torch.int64, device=dev)
+        src_global = _global_rank(self.group, src)
         if rank == src:
             off_t, ids_t, data_t = packed
             header[0], header[1], header[2] = off_t.numel() - 1, ids_t.numel(), int(data_t is not None)
-        dist.broadcast(header, src=src, group=self.group)
+        dist.broadcast(header, src=src_global, group=self.group)
         nq, nnz, has_data = (int(x) for x in header.tolist())
         total = (nq + 1) + nnz * (2 if has_data else 1)
         if rank == src:
@@ -199,7 +200,7 @@ class ShardedDatabase:
             buf = torch.cat(parts)
         else:
             buf = torch.empty(total, dtype=torch.int32, device=dev)
-        dist.broadcast(buf, src=src, group=self.group)
+        dist.broadcast(buf, src=src_global, group=self.group)
         off_t = buf[: nq + 1]
         ids_t = buf[nq + 1: nq + 1 + nnz]
         data_t = buf[nq + 1 + nnz:].view(torch.float32) if has_data else None
@@ -226,7 +227,7 @@ class ShardedDatabase:
             tensor = recv if recv is not None else torch.empty(plan.words, dtype=torch.int32,
                                                                device=self.engine.torch_device())
         if world > 1 or (force_collective and on):
-            dist.broadcast(tensor, src=src, group=self.group)
+            dist.broadcast(tensor, src=_global_rank(self.group, src), group=self.group)
         return self.engine.adopt(tensor, plan, self.width, into=into)
 
     # -- all-pairs: every rank needs every row as a candidate ---------------------------------
@@ -258,7 +259,7 @@ class ShardedDatabase:
         # stitch: offsets rebased by the elements of the shards before, then ids, then payloads
         offs, ids, datas, base = [], [], [], 0
         for p, w in zip(plans, wires):
-            o = w[: p.n_rows + 1].to(torch.int64) + base
+            o = (w[: p.n_rows + 1].to(torch.int64) & 0xFFFFFFFF) + base     # wire offsets are uint32 bit patterns
             offs.append(o if not offs else o[1:])
             ids.append(w[p.n_rows + 1: p.n_rows + 1 + p.nnz])
             if p.has_data:
@@ -339,33 +340,81 @@ class ShardedDatabase:
             _all_gather_ragged(slabs, local_counts.contiguous(), self.group)
         return torch.cat(slabs, dim=1)
 
-    def topk(self, local_counts, k: int):
-        """Per query, the k rows with the largest count over the WHOLE database: each rank
-        selects its local top-k, the (count, global row) candidates are all-gathered
-        (Q*k*16 bytes per rank) and merged.  Ties go to the lower row index.  The reference has
-        no top-k; this rule is this engine's own."""
+    def _merge_topk(self, counts, rows, k: int):
+        """Per query, the best k of the candidates (count int64 [Q][m], global row int64 [Q][m], row -1 = empty
+        slot) by count descending, then row ascending.  m is a few dozen: the sort key is a small tensor."""
+        import torch
+        span = self.n_rows_total + 1
+        key = torch.where(rows >= 0, counts * span + (self.n_rows_total - rows), torch.full_like(counts, -1))
+        kk = min(k, key.shape[1])
+        top_key, _ = torch.topk(key, kk, dim=1)
+        if kk < k:
+            top_key = torch.cat([top_key, torch.full((key.shape[0], k - kk), -1, dtype=torch.int64, device=key.device)], dim=1)
+        valid = top_key >= 0
+        out_counts = torch.where(valid, top_key // span, torch.zeros_like(top_key))
+        out_rows = torch.where(valid, self.n_rows_total - top_key % span, torch.full_like(top_key, -1))
+        return out_counts, out_rows
+
+    def _gather_candidates(self, counts, rows):
+        """All ranks' per-query candidate lists side by side: [Q][world * k]."""
         import torch
         import torch.distributed as dist
-
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return counts, rows
+        both = torch.stack([counts, rows]).contiguous()          # one collective for counts and rows
+        gathered = [torch.empty_like(both) for _ in range(world)]
+        dist.all_gather(gathered, both, group=self.group)
+        return torch.cat([g[0] for g in gathered], dim=1), torch.cat([g[1] for g in gathered], dim=1)
+
+    def query_topk(self, queries, k: int):
+        """Per query, the k rows of the WHOLE database with the largest id overlap (``ands`` on id-only views;
+        count descending, then lower row).  Each rank runs the fused all-pairs top-k kernel on its shard -- the
+        [Q][rows] count matrix is never written --, rebases the rows it found, and the Q*k candidates of every
+        rank are all-gathered (Q*k*16 bytes per rank) and merged.  Returns int64 ``(counts, rows)`` [Q][k],
+        empty slots (0, -1).  The fused kernel keeps 16 candidates per query: a larger k goes through the count
+        matrix of ``ands`` instead (same order for id-only batches).  The reference has no top-k; this rule is
+        this engine's own."""
+        import torch
+        kk = min(k, 16)
+        if kk < k:
+            return self.topk(self.size_op("ands", queries), k)    # the fused kernel keeps at most 16 per query
+        c, r = self.engine.allpairs_topk(queries, self.shard, kk, -1)
+        c, r = c.to(torch.int64), r.to(torch.int64)
+        r = torch.where(r >= 0, r + self.row_lo, r)
+        c, r = self._gather_candidates(c, r)
+        return self._merge_topk(c, r, k)
+
+    def topk(self, local_counts, k: int):
+        """The same selection from counts that already exist (``size_op`` output of this rank's shard): local
+        top-k per query -- in slabs of queries, so that the sort keys never take more than ~256 MB --, then the
+        all-gather and merge of :meth:`query_topk`."""
+        import torch
         n_local = local_counts.shape[1]
         kk = min(k, n_local)
         rows = torch.arange(self.row_lo, self.row_lo + n_local, device=local_counts.device, dtype=torch.int64)
-        # sort key: count descending, then row ascending
-        key = local_counts.to(torch.int64) * (self.n_rows_total + 1) + (self.n_rows_total - rows)[None, :]
-        top_key, _ = torch.topk(key, kk, dim=1)
+        span = self.n_rows_total + 1
+        slab = max(1, (32 << 20) // max(n_local, 1))
+        best_c, best_r = [], []
+        for q0 in range(0, local_counts.shape[0], slab):
+            part = local_counts[q0: q0 + slab].to(torch.int64)
+            key = part * span + (self.n_rows_total - rows)[None, :]      # count descending, then row ascending
+            top_key, _ = torch.topk(key, kk, dim=1)
+            best_c.append(top_key // span)
+            best_r.append(self.n_rows_total - top_key % span)
+        c, r = torch.cat(best_c), torch.cat(best_r)
         if kk < k:
-            pad = torch.full((top_key.shape[0], k - kk), -1, dtype=torch.int64, device=top_key.device)
-            top_key = torch.cat([top_key, pad], dim=1)
-        if world > 1:
-            gathered = [torch.empty_like(top_key) for _ in range(world)]
-            dist.all_gather(gathered, top_key.contiguous(), group=self.group)
-            top_key, _ = torch.topk(torch.cat(gathered, dim=1), k, dim=1)
-        valid = top_key >= 0
-        counts = torch.where(valid, top_key // (self.n_rows_total + 1), torch.zeros_like(top_key))
-        row_ids = torch.where(valid, self.n_rows_total - top_key % (self.n_rows_total + 1),
-                              torch.full_like(top_key, -1))
-        return counts, row_ids
+            pad = k - kk
+            c = torch.cat([c, torch.zeros((c.shape[0], pad), dtype=torch.int64, device=c.device)], dim=1)
+            r = torch.cat([r, torch.full((r.shape[0], pad), -1, dtype=torch.int64, device=r.device)], dim=1)
+        c, r = self._gather_candidates(c, r)
+        return self._merge_topk(c, r, k)
+
+
+def _global_rank(group, group_rank: int) -> int:
+    """``src`` of the collectives is a rank of the whole job; callers here count within ``group``."""
+    import torch.distributed as dist
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
 
 
 def _equal_shapes(tensors) -> bool:
@@ -378,4 +427,4 @@ def _all_gather_ragged(slabs, mine, group):
     for r, slab in enumerate(slabs):
         if r == dist.get_rank(group):
             slab.copy_(mine)
-        dist.broadcast(slab, src=r, group=group)
+        dist.broadcast(slab, src=_global_rank(group, r), group=group)

@@ -92,7 +92,11 @@ def test_damaged_files_are_refused(tmp_path):
     raw = bytearray(path.read_bytes())
     for what, mutate in [("magic", lambda b: b.__setitem__(0, ord("X"))),
                          ("truncated", lambda b: b.__delitem__(slice(len(b) - 40, len(b)))),
-                         ("rows", lambda b: b.__setitem__(slice(24, 32), (10 ** 12).to_bytes(8, "little")))]:
+                         ("rows", lambda b: b.__setitem__(slice(24, 32), (10 ** 12).to_bytes(8, "little"))),
+                         # n_rows + 1 wraps to zero offsets: must not pass as "fits"
+                         ("rows_wrap", lambda b: b.__setitem__(slice(24, 32), (2 ** 64 - 1).to_bytes(8, "little"))),
+                         # the offsets section moved onto the ids section (64-byte aligned, inside the file)
+                         ("overlap", lambda b: b.__setitem__(slice(56, 64), (64).to_bytes(8, "little")))]:
         damaged = bytearray(raw)
         mutate(damaged)
         bad = tmp_path / f"{what}.sdrb"

@@ -130,3 +130,52 @@ def test_sharded_driver_allpairs_single_rank():
     counts = oracle.port().size_op(oracle.AND, oracle.Batch(off, ids, None), oracle.Batch(off, ids, None))
     want_c, want_r = expected_topk(counts, 16, 0)
     assert np.array_equal(got_r.cpu().numpy(), want_r) and np.array_equal(got_c.cpu().numpy(), want_c)
+
+
+def test_sharded_query_topk_full_size_one_rank_with_collectives():
+    """4096 queries against a 1 Mi-row shard through ShardedDatabase.query_topk, with a one-rank RCCL group so
+    that the candidate all-gather really runs: the [Q][N] count matrix (17 GB) is never built -- device memory
+    taken beyond the inputs stays under 1 GB --, and sampled queries equal the oracle's order."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import oracle
+    import sdr_amd
+    from sdr_amd.shard import HipEngine, ShardedDatabase
+    nq, nd, width, active, k = 4096, 1 << 20, 2048, 40, 8
+    q_off, q_ids, _ = sdr_amd.synth_csr(2, 0, nq, width, active)
+    d_off, d_ids, _ = sdr_amd.synth_csr(1, 0, nd, width, active)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        engine = HipEngine(0)
+        db = ShardedDatabase.from_global_csr(d_off, d_ids, None, width=width, engine=engine, rank=0, world=1)
+        queries = engine.pack_host(q_off, q_ids, None, width)
+        warm = torch.ones(1, device="cuda:0")
+        dist.all_reduce(warm)                      # RCCL's own buffers are not this path's memory
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free_before, _ = torch.cuda.mem_get_info(0)
+        counts, rows = db.query_topk(queries, k)
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info(0)   # scratch and torch's cache are both still held: the peak
+        assert free_before - free_after < (1 << 30), (free_before - free_after) / 2 ** 20
+        assert counts.shape == (nq, k) and rows.dtype == torch.int64
+        rng = np.random.default_rng(3)
+        pick = np.sort(rng.choice(nq, 8, replace=False))
+        lo = q_off[pick].astype(np.int64)
+        sub_ids = np.concatenate([q_ids[a: a + active] for a in lo])
+        sub_off = np.arange(len(pick) + 1, dtype=np.uint64) * active
+        want = oracle.port().size_op(oracle.AND, oracle.Batch(sub_off, sub_ids, None), oracle.Batch(d_off, d_ids, None))
+        want_c, want_r = expected_topk(want, k, -1)
+        assert np.array_equal(counts.cpu().numpy()[pick], want_c) and np.array_equal(rows.cpu().numpy()[pick], want_r)
+        # and the selection from existing counts (slabs of queries) agrees on a slice of the queries
+        few = engine.pack_host(sub_off, sub_ids, None, width)
+        c2, r2 = db.topk(db.size_op("ands", few), k)
+        assert np.array_equal(c2.cpu().numpy(), want_c) and np.array_equal(r2.cpu().numpy(), want_r)
+    finally:
+        dist.destroy_process_group()

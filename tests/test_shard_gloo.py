@@ -135,6 +135,18 @@ def _worker(rank, world, port, with_data, n_rows, results, tmpdir):
         results[f"allpairs_{rank}"] = out[f"allpairs_{rank}"]
         counts, rows = db.topk(db.size_op("ands", queries), 5)
         out["topk_counts"], out["topk_rows"] = counts.numpy(), rows.numpy()
+        # the same selection straight from the queries (fused all-pairs top-k per shard, no count matrix); it ranks
+        # by id overlap, so with payloads the expectation comes from the id-only views of both sides
+        import oracle
+        id_only = lambda b: oracle.Batch(b.csr()[0], b.csr()[1], None)
+        id_counts = db.engine.size_op("ands", id_only(queries), id_only(db.shard))
+        want_counts, want_rows = db.topk(id_counts, 5)
+        if not with_data:
+            assert torch.equal(want_counts, counts) and torch.equal(want_rows, rows)
+        f_counts, f_rows = db.query_topk(queries, 5)
+        assert torch.equal(f_counts, want_counts) and torch.equal(f_rows, want_rows)
+        w_counts, w_rows = db.query_topk(queries, 20)       # more than the fused kernel keeps: falls back to counts
+        assert torch.equal(w_counts[:, :5], counts) and torch.equal(w_rows[:, :5], rows)
         if rank == 0:
             results.update(out)
         else:  # every rank must hold the same gathered result
@@ -195,3 +207,59 @@ def test_slice_csr_rebases_offsets():
     assert s_off.tolist() == [0, 0, 3] and s_ids.tolist() == [2, 3, 4] and s_data is None
     parts = [shard_range(10, r, 3) for r in range(3)]
     assert parts == [(0, 3), (3, 6), (6, 10)]
+
+
+def _subgroup_worker(rank, world, port, results):
+    """Ranks 1 and 2 of a three-rank job form the database's group: a rank within the group is not its rank in
+    the job, which is what the collectives' ``src`` must be given."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        group = dist.new_group([1, 2])
+        if rank == 0:
+            return
+        g_rank = dist.get_rank(group)
+        rng = np.random.default_rng(8)
+        d_off, d_ids, _ = util.ragged_rows(rng, 33, 200, 20, False)      # 16 + 17 rows: the ragged gather
+        q_off, q_ids, _ = util.ragged_rows(rng, 5, 200, 20, False)
+        db = ShardedDatabase.from_global_csr(d_off, d_ids, None, width=200, engine=OracleEngine(),
+                                             rank=g_rank, world=2, group=group)
+        packed = None
+        if g_rank == 1:      # the source is the group's second rank (job rank 2)
+            packed = (torch.from_numpy(q_off.astype(np.int64).astype(np.int32)), torch.from_numpy(q_ids), None)
+        queries = db.broadcast_queries(packed, src=1)
+        full = db.gather_counts(db.size_op("ands", queries))
+        wire = PackedQueries.from_host_csr(q_off, q_ids, None, width=200, engine=OracleEngine())
+        again = db.broadcast_packed(wire if g_rank == 1 else None, wire.plan, src=1)
+        assert np.array_equal(db.gather_counts(db.size_op("ands", again)).numpy(), full.numpy())
+        c, r = db.query_topk(queries, 3)
+        whole = db.gather_database()
+        assert np.array_equal(whole.csr()[0], d_off) and np.array_equal(whole.csr()[1], d_ids)
+        results[f"counts_{g_rank}"] = full.numpy()
+        results[f"topk_{g_rank}"] = (c.numpy(), r.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_database_group_inside_a_larger_job():
+    import oracle
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), results), nprocs=3, join=True)
+    rng = np.random.default_rng(8)
+    d = oracle.Batch(*util.ragged_rows(rng, 33, 200, 20, False))
+    q = oracle.Batch(*util.ragged_rows(rng, 5, 200, 20, False))
+    want = oracle.port().size_op(0, q, d)
+    for g_rank in range(2):
+        assert np.array_equal(results[f"counts_{g_rank}"].view(np.uint32), want)
+        c, r = results[f"topk_{g_rank}"]
+        for i in range(5):
+            order = sorted(range(33), key=lambda n: (-int(want[i, n]), n))[:3]
+            assert r[i].tolist() == order and c[i].tolist() == [int(want[i, n]) for n in order]
+
+
+def test_gathered_offsets_are_read_as_uint32():
+    """Wire offsets at or above 2^31 travel as negative int32; the stitch in gather_database must read them as
+    unsigned before rebasing."""
+    w = torch.tensor([0, -(2 ** 31), -1], dtype=torch.int32)
+    assert ((w.to(torch.int64) & 0xFFFFFFFF) + 5).tolist() == [5, 2 ** 31 + 5, 2 ** 32 + 4]
