@@ -16,6 +16,7 @@ SHAPES = {"c3": (2048, 40, False, 1 << 20), "c4": (16384, 328, True, 1 << 17)}
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = name.split("(")[0]
     return name if len(name) <= 90 else name[:87] + "..."
 
