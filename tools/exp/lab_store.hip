@@ -40,6 +40,38 @@ __global__ void k_tiles(uint32_t* out, size_t ld) {
     }
 }
 
+// (c') the same tiles with 16 bytes per lane after a 4x4 exchange inside each quad of lanes: lane 4g+r stores
+// columns 4g..4g+3 of row q0+r, so one instruction covers four rows x 256 B and a tile takes 16 instructions
+__global__ void k_tiles_quad(uint32_t* out, size_t ld) {
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const size_t j = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~3u);
+    const int r = threadIdx.x & 3;
+    for (int t = 0; t < Q / 64; ++t) {
+#pragma unroll
+        for (int q4 = 0; q4 < 16; ++q4) {
+            uint32_t* p = out + (size_t)(t * 64 + q4 * 4 + r) * ld + j;
+            v4 v = {(uint32_t)q4, (uint32_t)t, (uint32_t)r, (uint32_t)q4};
+            *(v4*)p = v;
+        }
+    }
+}
+// (c'') rows of a quad 8 apart (lane 4g+r stores row 8r+b): what the byte-sliced exchange of the count kernel yields
+__global__ void k_tiles_quad8(uint32_t* out, size_t ld) {
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const size_t j = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~3u);
+    const int r = threadIdx.x & 3;
+    for (int t = 0; t < Q / 64; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                uint32_t* p = out + (size_t)(t * 64 + 32 * h + 8 * r + b) * ld + j;
+                v4 v = {(uint32_t)b, (uint32_t)t, (uint32_t)r, (uint32_t)h};
+                *(v4*)p = v;
+            }
+    }
+}
+
 // (d) each block owns one contiguous chunk and sweeps it front to back
 template <int W>
 __global__ void k_chunked(uint32_t* out, size_t chunk_elems) {
@@ -70,6 +102,16 @@ float timeit(F f, int reps = 5) {
 int main(int argc, char** argv) {
     uint32_t* out; size_t bytes = (size_t)Q * N * 4;
     CK(hipMalloc(&out, bytes));
+    if (argc > 1 && argv[1][0] == 'q') {   // only the quad-exchange shapes against the dword tiles
+        auto rep = [&](const char* name, float ms) { printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+        rep("hipMemsetAsync", timeit([&] { CK(hipMemsetAsync(out, 1, bytes, 0)); }));
+        rep("tiles RPL1 block=256", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }));
+        rep("tiles quad (rows q0+r) block=256", timeit([&] { k_tiles_quad<<<N / 256, 256>>>(out, N); }));
+        rep("tiles quad8 (rows 8r+b) block=256", timeit([&] { k_tiles_quad8<<<N / 256, 256>>>(out, N); }));
+        rep("tiles RPL4 block=256", timeit([&] { k_tiles<4><<<N / 1024, 256>>>(out, N); }));
+        rep("tiles RPL1 block=256", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }));
+        return 0;
+    }
     if (argc > 1) {  // calibration mode for PMC runs: one known-size pattern, three launches
         for (int i = 0; i < 3; ++i) k_tiles<1><<<N / 256, 256>>>(out, N);
         CK(hipDeviceSynchronize());
