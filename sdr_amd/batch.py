@@ -86,6 +86,11 @@ class ElemResult:
     def data(self):
         return None if self.data_buffer is None else self.data_buffer[: self.total]
 
+    def ids_as(self, dtype):
+        """The ids in another integer type -- the reference's ``ande<SDRElem<long>, ...>`` and friends, which
+        retarget the id type of the result (SDR.hpp:151-152; /root/reference/src/test.cpp:204-229)."""
+        return self.ids.to(dtype)
+
     def to_host(self):
         off = self.offsets.cpu().numpy().view(np.uint32).astype(np.uint64)
         ids = self.ids.cpu().numpy()
@@ -564,9 +569,51 @@ class SDRBatch:
         """Every row becomes ``row.xori(other[j])`` (SDR.hpp:1366-1422)."""
         return self._inplace("xore", other, stream)
 
-    def rmi(self, other, *, stream=None) -> "SDRBatch":
-        """Every row becomes ``row.rmi(other[j])`` (SDR.hpp:1436-1513)."""
-        return self._inplace("rme", other, stream)
+    def rmi(self, other, *, combine=None, stream=None) -> "SDRBatch":
+        """Every row becomes ``row.rmi(other[j])`` (SDR.hpp:1436-1513).
+
+        ``combine`` is the reference's ``rmi_combiner`` (SDR.hpp:304-310, 1447-1513) in batched form: it is called
+        ONCE with the payloads of all common ids -- ``combine(this_values, arg_values)``, float32 device tensors
+        in row order, ascending ids within a row (``arg_values`` is None for an EmptyData argument) -- and returns
+        the new payloads of those elements of ``this``; an element whose new payload is not ``rm_relevant`` (below
+        0.1 for UnitData, UnitData.hpp:22-28; never for ArithData, ArithData.hpp:22-28) is removed, every other
+        element stays.  The default combiner is the payload type's own ``rmi``."""
+        if combine is None:
+            return self._inplace("rme", other, stream)
+        if self.data_kind == DATA_EMPTY:
+            raise ValueError("a combiner needs payloads on this batch (EmptyData has nothing to combine)")
+        if self.id_bits != 32 or other.id_bits != 32:
+            raise ValueError("rmi with a combiner serves batches with 32-bit ids")
+        torch = _torch()
+        hits = self.andv(other, rowwise=True, stream=stream)
+        wire = self.to_wire(stream=stream)
+        n, nnz = self.n_rows, self.nnz
+        off = wire[: n + 1].to(torch.int64) & 0xFFFFFFFF
+        ids, data = wire[n + 1: n + 1 + nnz], wire[n + 1 + nnz:].view(torch.float32).clone()
+        # positions are per row: make them positions in the element arrays
+        lens = hits.offsets.to(torch.int64) & 0xFFFFFFFF
+        row_of_hit = torch.repeat_interleave(torch.arange(n, device=wire.device), lens[1:] - lens[:-1])
+        t_at = (hits.this_pos.to(torch.int64) & 0xFFFFFFFF) + off[row_of_hit]
+        arg_vals = None
+        if other.data_kind != DATA_EMPTY:
+            o_wire = other.to_wire(stream=stream)
+            o_off = o_wire[: other.n_rows + 1].to(torch.int64) & 0xFFFFFFFF
+            o_data = o_wire[other.n_rows + 1 + other.nnz:].view(torch.float32)
+            arg_vals = o_data[(hits.arg_pos.to(torch.int64) & 0xFFFFFFFF) + o_off[row_of_hit]]
+        new_vals = combine(data[t_at], arg_vals)
+        if new_vals.dtype != torch.float32 or new_vals.shape != t_at.shape:
+            raise ValueError("the combiner must return one float32 payload per common id")
+        data[t_at] = new_vals
+        keep = torch.ones(nnz, dtype=torch.bool, device=wire.device)
+        if self.data_kind == _KINDS["unit"]:
+            keep[t_at] = new_vals >= 0.1        # binary32 compare: same verdict as the reference's double compare
+        # new row starts: how many kept elements precede each old row start
+        kept_upto = torch.cat([torch.zeros(1, dtype=torch.int64, device=wire.device), torch.cumsum(keep, 0)])
+        new_off = kept_upto[off]
+        new_off32 = torch.where(new_off >= 2 ** 31, new_off - 2 ** 32, new_off).to(torch.int32)
+        self.upload_device(new_off32, ids[keep].contiguous(), data[keep].contiguous(), stream=stream)
+        self._refresh_info()
+        return self
 
     def equals(self, other: "SDRBatch", *, rowwise=False, stream=None):
         """``out[i, j] = (self[i] == other[j])`` as 0/1 (int32), the reference's ``operator==`` (SDR.hpp:470-483):
@@ -651,17 +698,75 @@ class SDRBatch:
     def __isub__(self, other):
         return self.rmi(other)
 
-    def ande(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
-        return self._elem_op(OP_AND, other, swap, stream, algo)
+    # -- views of a batch under another payload type ------------------------------------------------
+    def _view(self, kind, data_t, stream):
+        torch = _torch()
+        if self.id_bits != 32:
+            raise ValueError("views exist for batches with 32-bit ids")
+        wire = self.to_wire(stream=stream)
+        n, nnz = self.n_rows, self.nnz
+        st = self.stats()
+        v = SDRBatch(self.device, self.width, kind)
+        if data_t is None and kind != "empty":
+            data_t = torch.ones(nnz, dtype=torch.float32, device=wire.device)
+        v.adopt_device(wire[: n + 1], wire[n + 1: n + 1 + nnz], data_t if kind != "empty" else None,
+                       max_row_len=st["max_row_len"], min_id=st["min_id"], max_id=st["max_id"])
+        return v
 
-    def ore(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
-        return self._elem_op(OP_OR, other, swap, stream, algo)
+    def ids_only(self, *, stream=None) -> "SDRBatch":
+        """The same rows as an EmptyData batch (a device copy of offsets and ids; payloads dropped)."""
+        return self if self.data_kind == DATA_EMPTY else self._view("empty", None, stream)
 
-    def xore(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
-        return self._elem_op(OP_XOR, other, swap, stream, algo)
+    def as_unit(self, *, stream=None) -> "SDRBatch":
+        """An EmptyData batch as UnitData: every element gets ``UnitData(EmptyData)`` = 1 (UnitData.hpp:13-14)."""
+        if self.data_kind != DATA_EMPTY:
+            raise ValueError("as_unit converts EmptyData batches")
+        return self._view("unit", None, stream)
 
-    def rme(self, other, *, swap=False, stream=None, algo=None) -> ElemResult:
-        return self._elem_op(OP_RM, other, swap, stream, algo)
+    def _elem_op_ret(self, op, other, ret, swap, stream, algo):
+        """Element op with the reference's result-type argument (``ande<ret_t, c_ret_t>``, SDR.hpp:151-152,
+        209-212, 237-240, 292-293).  ``ret``: None keeps ``this``'s payload type; "empty": the data of a match is
+        converted to EmptyData before its relevance is asked, so the payloads play no part (EmptyData.hpp:27-37:
+        intersections keep every common id, xore and rme drop every common id); "unit" on an EmptyData ``this``:
+        a match gets ``EmptyData::op<UnitData>()`` = ``UnitData()`` = 1 and is kept (EmptyData.hpp:44-45,53-54,
+        64-65; 1 is relevant), elements of ``this`` alone become ``UnitData(EmptyData)`` = 1, elements of the
+        argument alone keep their payload -- for ore AND xore that is the union with ones on ``this``'s side;
+        rme has no such form (``EmptyData::rme`` returns EmptyData whatever is asked for, EmptyData.hpp:73-74)."""
+        if ret is None:
+            return self._elem_op(op, other, swap, stream, algo)
+        if swap:
+            raise ValueError("a result type is chosen for this.op(arg): evaluate the swapped call on the other batch")
+        if ret == "empty":
+            return self.ids_only(stream=stream)._elem_op(op, other.ids_only(stream=stream), False, stream, algo)
+        if ret != "unit":
+            raise ValueError('ret must be None, "empty" or "unit"')
+        if self.data_kind != DATA_EMPTY:
+            if self.data_kind != _KINDS["unit"]:
+                raise ValueError('ret="unit" needs an EmptyData or UnitData batch')
+            return self._elem_op(op, other, False, stream, algo)
+        if op == OP_RM:
+            raise ValueError("rme of an EmptyData batch yields EmptyData whatever result type is asked for")
+        if op == OP_AND:
+            res = self._elem_op(op, other.ids_only(stream=stream), False, stream, algo)
+            if isinstance(res, ChunkedElemResult):
+                for c in res.chunks:
+                    c.data_buffer = _torch().ones_like(c.ids_buffer, dtype=_torch().float32)
+            else:
+                res.data_buffer = _torch().ones_like(res.ids_buffer, dtype=_torch().float32)
+            return res
+        return self.as_unit(stream=stream)._elem_op(OP_OR, other, False, stream, algo)
+
+    def ande(self, other, *, swap=False, stream=None, algo=None, ret=None) -> ElemResult:
+        return self._elem_op_ret(OP_AND, other, ret, swap, stream, algo)
+
+    def ore(self, other, *, swap=False, stream=None, algo=None, ret=None) -> ElemResult:
+        return self._elem_op_ret(OP_OR, other, ret, swap, stream, algo)
+
+    def xore(self, other, *, swap=False, stream=None, algo=None, ret=None) -> ElemResult:
+        return self._elem_op_ret(OP_XOR, other, ret, swap, stream, algo)
+
+    def rme(self, other, *, swap=False, stream=None, algo=None, ret=None) -> ElemResult:
+        return self._elem_op_ret(OP_RM, other, ret, swap, stream, algo)
 
 
 def synth_csr(seed: int, first_row: int, n_rows: int, width: int, active: int, with_data: bool = False):
