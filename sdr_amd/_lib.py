@@ -17,6 +17,7 @@ DATA_EMPTY, DATA_UNIT, DATA_ARITH = 0, 1, 2
 FLAG_SWAP, FLAG_FORCE_MERGE, FLAG_FORCE_BITSLICE, FLAG_FORCE_POPCOUNT, FLAG_FORCE_MFMA, FLAG_ROWWISE, FLAG_FORCE_ROWTABLE = 1, 2, 4, 8, 16, 32, 64
 FLAG_FORCE_RANK = 128
 FLAG_FORCE_BITMAP, FLAG_FORCE_LANEMERGE, FLAG_FORCE_LANERANK = 256, 512, 1024
+FLAG_FORCE_SPARSE = 2048
 
 ERROR_NAMES = {
     -1: "SDRB_ERR_INVALID_ARG",

@@ -393,7 +393,7 @@ class SDRBatch:
                                          _stream_handle(self.device, stream)))
         return out[: ids.size, : self.n_rows]
 
-    def inner(self, other: "SDRBatch", *, out=None, stream=None):
+    def inner(self, other: "SDRBatch", *, out=None, stream=None, algo=None):
         """``out[i, j] = self[i].inner(other[j])`` (float32): the sparse dot product over the id
         matches in ascending id order, product and sum rounded separately, bit-exact against the
         reference (``SDR.hpp:1682-1692``).  ``self`` must be an "arith" batch, ``other`` "arith" or
@@ -406,7 +406,8 @@ class SDRBatch:
         if out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] < self.n_rows \
                 or out.shape[1] < other.n_rows or out.stride(1) != 1:
             raise ValueError("out must be a float32 [>=na, >=nb] tensor with unit inner stride")
-        check(self._lib.sdrb_inner(self._h, other._h, 0, out.data_ptr(), out.stride(0),
+        flags = {None: 0, "sparse": _lib.FLAG_FORCE_SPARSE, "table": FLAG_FORCE_ROWTABLE, "merge": FLAG_FORCE_MERGE}[algo]
+        check(self._lib.sdrb_inner(self._h, other._h, flags, out.data_ptr(), out.stride(0),
                                    _stream_handle(other.device, stream)))
         return out
 

@@ -990,7 +990,6 @@ int sdrb_point_query(const sdrb_batch* b, uint64_t n_ids, const int32_t* ids, in
 
 int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
                void* stream) {
-    (void)flags;
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_inner");
     if (rc != SDRB_OK) return rc;
@@ -1009,7 +1008,7 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
         set_error("hipSetDevice(%d) failed", b->device);
         return SDRB_ERR_HIP;
     }
-    return launch_inner(a, b, out, ld_out, static_cast<hipStream_t>(stream));
+    return launch_inner(a, b, flags, out, ld_out, static_cast<hipStream_t>(stream));
 }
 
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,

@@ -317,9 +317,23 @@ bool table_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 
 }  // namespace
 
-int launch_inner(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t ld_out, hipStream_t stream) {
+int launch_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
+                 hipStream_t stream) {
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
-    if (a->n_rows <= kFewRows && b->width > 0 && b->max_row_len <= 64 && a->max_row_len < 8192) {
+    const bool want_sparse = (flags & SDRB_FLAG_FORCE_SPARSE) != 0, want_dense = (flags & SDRB_FLAG_FORCE_ROWTABLE) != 0;
+    const bool want_merge = (flags & SDRB_FLAG_FORCE_MERGE) != 0;
+    if (want_sparse) {
+        if (!inner_sparse_applicable(a, b, true)) {
+            set_error("sdrb_inner: the match-visiting kernel needs a declared width <= 4096, rows of b <= 64 ids and rows of a <= 128 ids");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_inner_sparse(a, b, out, ld_out, stream);
+    }
+    if (want_dense && !table_applicable(a, b)) {
+        set_error("sdrb_inner: the value-table kernel needs a declared width <= 4096 and rows of b <= 64 ids");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (!want_dense && !want_merge && a->n_rows <= kFewRows && b->width > 0 && b->max_row_len <= 64 && a->max_row_len < 8192) {
         const uint32_t width = (uint32_t)b->width;
         const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
         const uint32_t val_cap = (uint32_t)a->n_rows * (longest ? longest : 1u);   // < 65536: col[] is 16 bit
@@ -347,7 +361,8 @@ int launch_inner(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t 
             return SDRB_OK;
         }
     }
-    if (!table_applicable(a, b)) {
+    if (!want_dense && !want_merge && inner_sparse_applicable(a, b, false)) return launch_inner_sparse(a, b, out, ld_out, stream);
+    if (want_merge || !table_applicable(a, b)) {
         const dim3 grid((uint32_t)((b->n_rows + kBlock - 1) / kBlock), (uint32_t)a->n_rows);
         if (a->n_rows > 65535) {
             set_error("sdrb_inner: more than 65535 rows of A need a declared width <= 4096 and rows of B <= 64 ids");

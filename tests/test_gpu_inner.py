@@ -106,3 +106,49 @@ def test_inner_few_rows_against_a_long_database():
                        np.concatenate([data[int(off[r]):int(off[r + 1])] for r in rows]))
     want = oracle.port().inner(oracle.Batch(*t_csr), sub)
     assert np.array_equal(got[:, rows], want.view(np.uint32))
+
+
+@pytest.mark.parametrize("width,len_t,len_a,nt,na", [(2048, 40, 40, 37, 1000), (4096, 64, 64, 70, 700), (300, 100, 16, 130, 513),
+                                                     (2048, 128, 64, 33, 300), (64, 64, 64, 40, 257), (2048, 0, 40, 5, 300),
+                                                     (2000, 40, 0, 64, 300)])
+def test_inner_kernels_agree_with_the_oracle(width, len_t, len_a, nt, na):
+    """The match-visiting kernel (32-row mask tiles), the dense value-table kernel and the per-pair merge on the
+    same batches: partial tiles of A, partial blocks of B, rows of A longer than a wave, dense small widths where
+    most ids of a tile are taken, empty rows and empty sides."""
+    import oracle
+    from sdr_amd import SDRBatch
+    rng = np.random.default_rng(width + nt + len_t)
+    t_csr = util.arith_rows(rng, nt, width, len_t) if len_t else (np.zeros(nt + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    a_csr = util.arith_rows(rng, na, width, len_a) if len_a else (np.zeros(na + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    t = SDRBatch.from_csr(*t_csr, width=width, kind="arith")
+    a = SDRBatch.from_csr(*a_csr, width=width, kind="arith")
+    a_ids_only = SDRBatch.from_csr(a_csr[0], a_csr[1], None, width=width)
+    want = oracle.port().inner(oracle.Batch(*t_csr), oracle.Batch(*a_csr)).view(np.uint32)
+    want_e = oracle.port().inner(oracle.Batch(*t_csr), oracle.Batch(a_csr[0], a_csr[1], None)).view(np.uint32)
+    for algo in ("sparse", "table", "merge"):
+        assert np.array_equal(bits(t.inner(a, algo=algo)), want), algo
+        assert np.array_equal(bits(t.inner(a_ids_only, algo=algo)), want_e), algo
+
+
+def test_inner_sparse_kernel_special_values_and_golden(golden):
+    import oracle
+    from sdr_amd import SDRBatch, SdrbError
+    g = golden("inner.npz")
+    for tag, width in (("small", 64), ("c2like", 2048)):
+        t = SDRBatch.from_csr(g[f"{tag}_t_off"], g[f"{tag}_t_ids"], g[f"{tag}_t_data"], width=width, kind="arith")
+        a = SDRBatch.from_csr(g[f"{tag}_a_off"], g[f"{tag}_a_ids"], g[f"{tag}_a_data"], width=width, kind="arith")
+        assert np.array_equal(bits(t.inner(a, algo="sparse")), g[f"{tag}_aa_bits"])
+    # signed zeros, denormals, cancellation, overflow to infinity inside a sum
+    off = np.array([0, 4, 8], np.uint64)
+    ids = np.array([1, 2, 3, 9, 1, 2, 3, 9], np.int32)
+    t_data = np.array([-0.0, 1e-40, 3e38, 3e38, 1.0, -1.0, 1e20, 1e20], np.float32)
+    a_data = np.array([5.0, 1e-5, 2.0, 2.0, -0.0, 0.0, 1e20, -1e20], np.float32)
+    want = oracle.port().inner(oracle.Batch(off, ids, t_data), oracle.Batch(off, ids, a_data))
+    t = SDRBatch.from_csr(off, ids, t_data, width=16, kind="arith")
+    a = SDRBatch.from_csr(off, ids, a_data, width=16, kind="arith")
+    assert np.array_equal(bits(t.inner(a, algo="sparse")), want.view(np.uint32))
+    rng = np.random.default_rng(1)
+    long_t = SDRBatch.from_csr(*util.arith_rows(rng, 3, 4096, 300), width=4096, kind="arith")
+    some_a = SDRBatch.from_csr(*util.arith_rows(rng, 9, 4096, 40), width=4096, kind="arith")
+    with pytest.raises(SdrbError):          # rows of `this` beyond what a tile's value store holds
+        long_t.inner(some_a, algo="sparse")
