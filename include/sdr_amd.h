@@ -74,8 +74,10 @@ extern "C" {
 #define SDRB_FLAG_FORCE_BITMAP 256u   /* element fill: fail with UNSUPPORTED unless the dense-bitset fill applies */
 #define SDRB_FLAG_FORCE_LANEMERGE 512u /* element fill: fail with UNSUPPORTED unless the lane-per-pair merge fill (unions of short rows, ids only) applies */
 #define SDRB_FLAG_FORCE_LANERANK 1024u /* element fill: fail with UNSUPPORTED unless the lane-per-pair rank fill (unions of short rows, ids only, width <= 4096) applies */
-#define SDRB_FLAG_FORCE_SPARSE 2048u /* sdrb_inner: fail with UNSUPPORTED unless the match-visiting kernel applies (FORCE_ROWTABLE there:
-                                        the dense value-table kernel; FORCE_MERGE: the per-pair merge) */
+#define SDRB_FLAG_FORCE_SPARSE 2048u /* sdrb_inner, size ops: fail with UNSUPPORTED unless the lane-per-row match kernel applies
+                                        (sdrb_inner also takes FORCE_ROWTABLE: the dense value-table kernel, and FORCE_MERGE:
+                                        the per-pair merge) */
+#define SDRB_FLAG_FORCE_MASKTABLE 4096u /* size ops: fail with UNSUPPORTED unless the 64-row mask-table kernel applies */
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;

@@ -324,9 +324,13 @@ class SDRBatch:
             f |= FLAG_FORCE_LANEMERGE
         elif algo == "lanerank":    # element fill by the lane-per-pair rank kernel
             f |= FLAG_FORCE_LANERANK
+        elif algo == "lanerows":    # size ops with payloads by the lane-per-row match kernel
+            f |= _lib.FLAG_FORCE_SPARSE
+        elif algo == "masktable":   # size ops by the 64-row mask-table kernel
+            f |= _lib.FLAG_FORCE_MASKTABLE
         elif algo is not None:
             raise ValueError("algo must be None, 'merge', 'bitslice', 'popcount', 'rowtable', 'rank', 'bitmap', "
-                             "'lanemerge' or 'lanerank'")
+                             "'lanemerge', 'lanerank', 'lanerows' or 'masktable'")
         return f
 
     def _size_op(self, op: int, other: "SDRBatch", swap: bool, out, stream, algo):

@@ -755,6 +755,18 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (rowwise || a->id_bits == 64) return launch_size_merge(a, b, op, swap, out, ld_out, rowwise, s);
+    if ((flags & SDRB_FLAG_FORCE_MASKTABLE) && !mask_table_applicable(a, b)) {
+        set_error("mask-table kernel requested but not applicable (needs a declared width whose table fits LDS)");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (flags & SDRB_FLAG_FORCE_SPARSE) {
+        if (!size_lane_rows_applicable(a, b, op, swap, true)) {
+            set_error("lane-per-row match kernel requested but not applicable (payload-dependent op, width <= 4096, "
+                      "rows of b <= 64 ids, rows of a <= 128 ids)");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_size_lane_rows(a, b, op, swap, out, ld_out, s);
+    }
     if (flags & SDRB_FLAG_FORCE_POPCOUNT) {
         if (a->id_bits != 32 || !id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
             set_error("popcount kernel requested but not applicable to these batches/op");
@@ -767,6 +779,9 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         // rows too long for the bit-sliced kernel: the popcount kernel's cost does not depend on row length
         if (id_only(a, b, op, swap) && popcount_applicable(a, b))
             return launch_size_popcount(a, b, op, swap, out, ld_out, s);
+        // payloads on short sparse rows: every match visited once by the lane that owns the row of B
+        if (!(flags & (SDRB_FLAG_FORCE_ROWTABLE | SDRB_FLAG_FORCE_MASKTABLE)) && size_lane_rows_applicable(a, b, op, swap, false))
+            return launch_size_lane_rows(a, b, op, swap, out, ld_out, s);
         // payloads or long rows: with several rows of A the 64-row mask table reads B once for all of them
         if (!(flags & SDRB_FLAG_FORCE_ROWTABLE) && mask_table_applicable(a, b))
             return launch_size_mask_table(a, b, op, swap, out, ld_out, s);

@@ -21,8 +21,8 @@
 #include <initializer_list>
 #include <type_traits>
 
-#include "sdrb_device.h"
 #include "sdrb_internal.h"
+#include "match_math.h"
 
 namespace sdrb {
 
@@ -35,33 +35,6 @@ constexpr int kRowsPerWave = kGroup / kWaves;    // 4
 // rows of A per mask table: 64, or 32 where that makes room for the tile's payloads in LDS;
 // counter tile: [row of B][row of A], padded by one word against bank conflicts
 constexpr int cnt_ld(int tile) { return tile + 1; }
-
-// How a match's payload decides whether it is kept; `t` is the payload of `this`
-// (same classification as unit_table.hip).
-enum Math { kKeepAll, kDropAll, kSelfA, kSelfB, kMul, kAbsDiff, kRmulA, kRmulB };
-
-template <int MATH>
-__device__ __forceinline__ bool match_kept_by(float va, float vb, float& d) {
-    d = 0.0f;
-    if constexpr (MATH == kKeepAll) return true;
-    else if constexpr (MATH == kDropAll) return false;
-    else {
-        if constexpr (MATH == kSelfA) d = va;
-        else if constexpr (MATH == kSelfB) d = vb;
-        else if constexpr (MATH == kMul) d = va * vb;
-        else if constexpr (MATH == kAbsDiff) d = fabsf(va - vb);
-        else if constexpr (MATH == kRmulA) { const float om = 1.0f - vb; d = va * om; }
-        else { const float om = 1.0f - va; d = vb * om; }
-        return unit_relevant(d);
-    }
-}
-
-__device__ __forceinline__ uint32_t size_of(int op, uint32_t l_this, uint32_t l_arg, uint32_t m, uint32_t k) {
-    if (op == SDRB_OP_AND) return k;
-    if (op == SDRB_OP_OR) return l_this + l_arg - m;
-    if (op == SDRB_OP_XOR) return l_this + l_arg - 2 * m + k;
-    return l_this - m + k;
-}
 
 // dense payload matrix of A: val[i][w] = payload of id w in row i (only read where mask says so)
 __global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restrict__ a_off,
@@ -638,17 +611,6 @@ __global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__
             }
         }
     }
-}
-
-int pick_math(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
-    const bool au = a->data_kind == SDRB_DATA_UNIT, bu = b->data_kind == SDRB_DATA_UNIT;
-    const bool this_unit = swap ? bu : au, arg_unit = swap ? au : bu;
-    if (op == SDRB_OP_OR) return kKeepAll;
-    if (!this_unit) return op == SDRB_OP_AND ? kKeepAll : kDropAll;
-    if (!arg_unit) return swap ? kSelfB : kSelfA;
-    if (op == SDRB_OP_AND) return kMul;
-    if (op == SDRB_OP_XOR) return kAbsDiff;
-    return swap ? kRmulB : kRmulA;
 }
 
 size_t lds_bytes(uint32_t width, int tile = 64) {

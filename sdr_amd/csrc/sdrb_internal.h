@@ -213,9 +213,13 @@ int launch_transpose(const sdrb_batch* src, uint32_t* dst_off, int32_t* dst_ids,
 // Sparse dot products of ArithData<float> rows for every pair (SDR::inner, SDR.hpp:1682-1692).
 int launch_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
                  hipStream_t stream);
-// inner_sparse.hip: the same numbers by visiting id matches only (32-row mask tiles of A in LDS, a lane per row of B)
+// lane_rows.hip: the same numbers by visiting id matches only (32-row mask tiles of A in LDS, a lane per row of B),
+// and the payload-dependent size operations by the same walk
 bool inner_sparse_applicable(const sdrb_batch* a, const sdrb_batch* b, bool forced);
 int launch_inner_sparse(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t ld_out, hipStream_t stream);
+bool size_lane_rows_applicable(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, bool forced);
+int launch_size_lane_rows(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out, uint64_t ld_out,
+                          hipStream_t stream);
 
 // unit_table.hip --------------------------------------------------------------------
 // Wave-per-row kernels with an LDS position table of one row of A (declared width <= 32768).

@@ -497,12 +497,43 @@ def test_mask_table_kernel_many_tiles_and_groups(name, width, max_len):
         want = oracle.port().size_op(op, t, a)
         assert np.array_equal(gpu_sizes(op, dt, da), want), op
         assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), op
+        if width <= 20000:      # the table fits LDS: the kernel by name, whatever the default choice is
+            assert np.array_equal(gpu_sizes(op, dt, da, algo="masktable"), want), op
+            assert np.array_equal(gpu_sizes(op, dt, da, swap=True, algo="masktable"), oracle.port().size_op(op, a, t).T), op
     # ande through the mask-table fill (slots claimed concurrently, then sorted per pair)
     assert_elems_equal(gpu_elems(AND, dt, da), oracle.port().elem_op(AND, t, a))
     off, ids, data = gpu_elems(AND, dt, da, swap=True)
     w_off, w_ids, w_data = oracle.port().elem_op(AND, a, t)
     assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
                           util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["UU", "UE", "EU"])
+@pytest.mark.parametrize("width,len_t,len_a,nt,na", [(2048, 40, 40, 150, 700), (4096, 128, 64, 33, 300), (300, 100, 16, 70, 513),
+                                                     (64, 64, 64, 40, 257), (2048, 0, 40, 20, 300), (2000, 40, 0, 64, 300),
+                                                     (4000, 10, 33, 17, 100)])
+def test_lane_rows_size_kernel_vs_oracle(name, width, len_t, len_a, nt, na):
+    """Payload-dependent size ops by the lane-per-row match kernel: partial tiles of A and blocks of B, rows of A
+    longer than a wave, widths where most ids of a tile are taken, empty sides; both orientations."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(7 + 2 * tu + au + width + len_t)
+    t = Batch(*util.ragged_rows(rng, nt, width, len_t, tu)) if len_t else Batch(np.zeros(nt + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if tu else None)
+    a = Batch(*util.ragged_rows(rng, na, width, len_a, au)) if len_a else Batch(np.zeros(na + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if au else None)
+    dt, da = dev(t, width), dev(a, width)
+    served = 0
+    for op in range(4):
+        for swap in (False, True):
+            this_unit = au if swap else tu
+            if op == OR or not this_unit:       # ids alone decide: not this kernel's case, it must refuse
+                with pytest.raises(sdr_amd.SdrbError):
+                    gpu_sizes(op, dt, da, swap=swap, algo="lanerows")
+                continue
+            want = oracle.port().size_op(op, a, t).T if swap else oracle.port().size_op(op, t, a)
+            assert np.array_equal(gpu_sizes(op, dt, da, swap=swap, algo="lanerows"), want), (op, swap)
+            assert np.array_equal(gpu_sizes(op, dt, da, swap=swap), want), (op, swap)
+            served += 1
+    assert served >= 3
 
 
 @pytest.mark.gpu

@@ -15,7 +15,7 @@ q = SDRBatch.from_csr(*sdr_amd.synth_csr(2, 0, nq, 2048, 40, True), width=2048)
 d = SDRBatch.from_csr(*sdr_amd.synth_csr(1, 0, nd, 2048, 40, True), width=2048)
 out = torch.empty((nq, nd), dtype=torch.int32, device="cuda:0")
 for name in ("ands", "ors", "xors", "rms"):
-    for algo in (None, "rowtable"):
+    for algo in (None, "masktable"):
         fn = lambda: getattr(q, name)(d, out=out, algo=algo)   # noqa: E731
         fn()
         torch.cuda.synchronize()
