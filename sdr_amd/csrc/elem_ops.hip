@@ -190,7 +190,7 @@ namespace {
 // bits; (2) one workgroup scans the tile sums (a few thousand values) and writes the grand total; (3) every
 // tile scans its entries locally, starting from its tile's prefix.  The entries are read twice -- the second
 // time out of the Infinity Cache for arrays that fit it -- and written once.  (A single-pass variant with
-// chained tiles and decoupled look-back was measured slower here: 70 us against 50 us on 16.7 M entries; the
+// chained tiles and decoupled look-back was measured slower here: 70 us against 40 us on 16.7 M entries; the
 // polling of a few status lines by hundreds of resident workgroups is what held it back.)
 // Offsets are kept modulo 2^32; the 64-bit total tells the caller whether they are valid.
 constexpr int kScanSlabs = 4;                        // a thread holds 4 consecutive entries of each slab

@@ -1,3 +1,5 @@
+// Perf lab (not shipped): sdr_amd/csrc/allpairs_mfma.hip plus timing-experiment switches (SDRB_AP_EXP_*, SDRB_AP_FORCE_SPLITS).
+// Keep in step with the product file by hand; built by tools/exp/build_ap_variant.sh.
 // All-pairs overlap as a dense int8 0/1 matrix product on the matrix cores, with the per-row
 // top-k selection fused into the epilogue so the na x nb count matrix is never written.
 //
@@ -83,6 +85,16 @@ __device__ __forceinline__ void stage_dma(const i32x4* __restrict__ src_j, const
     }
 }
 
+#ifdef SDRB_AP_EXP_STAMPS   // diagnostic build only: cycles of block 0 / wave 0 spent in each phase
+}  // (leave the unnamed namespace so the symbol is sdrb::g_ap_stamps)
+__device__ unsigned long long g_ap_stamps[8];
+namespace {
+#define AP_STAMP(slot, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ap_stamps[slot] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define AP_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define AP_STAMP(slot, t0) do { (void)(t0); } while (0)
+#define AP_NOW() 0ull
+#endif
 
 template <int LIST>
 __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
@@ -136,14 +148,24 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0;
         const bool last_panel = jp + 1 == jp_end;
+        const unsigned long long t_loop = AP_NOW();
         for (uint32_t st = 0; st < n_stages; ++st) {
             const bool last_stage = st + 1 == n_stages;
+#ifdef SDRB_AP_EXP_NO_DMA   // timing experiment: multiply whatever the buffers hold
+            if (false) {
+#else
             if (!(last_stage && last_panel)) {
+#endif
                 // the other buffer was last read (or used as parking space) before the previous barrier
                 const uint32_t st_next = last_stage ? 0 : st + 1;
                 stage_dma(dense_j + ((uint64_t)(last_stage ? jp + 1 : jp) * n_chunks + 2 * st_next) * kPieceVec,
                           gi + (uint64_t)(2 * st_next) * kPieceVec, &lds[buf ^ 1][0][0], &lds[buf ^ 1][1][0], tid, wave);
             }
+#ifdef SDRB_AP_EXP_NO_MFMA   // timing experiment: operand delivery only
+            __syncthreads();
+            buf ^= 1;
+            continue;
+#endif
             i32x4 fa[2][4], fb[2][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -170,7 +192,10 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
             buf ^= 1;
         }
 
+        AP_STAMP(0, t_loop);
+        const unsigned long long t_epi = AP_NOW();
         // ---- epilogue (once per j panel): fold this 128 x 128 wave tile into the per-lane top-k lists
+#ifndef SDRB_AP_EXP_NO_EPILOGUE
         {
             const uint32_t j_local0 = (jp - jp_begin) * kPanel + wm * 128 + 4 * half;   // local j of (mt 0, reg 0)
             const long long j_lo = (long long)jp * kPanel + wm * 128;                    // first global j of the wave tile
@@ -188,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
             i32x4* park = &lds[buf ^ 1][0][0] + wave * 1024 + lane;   // [slot / 4][lane]
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
+                const unsigned long long t_park = AP_NOW();
                 __builtin_amdgcn_sched_barrier(0);   // keep these accumulator reads next to their stores
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -197,6 +223,12 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
                         park[(mt * 4 + q) * 64] = i32x4{t16[4 * q], t16[4 * q + 1], t16[4 * q + 2], t16[4 * q + 3]};
                     }
                 __builtin_amdgcn_sched_barrier(0);
+                AP_STAMP(3, t_park);
+                const unsigned long long t_pre = AP_NOW();
+#ifdef SDRB_AP_EXP_PARK_ONLY   // timing experiment: stop after parking
+                if (park[0][0] == 0x7fffffff) list[nt][0] = 1;
+                continue;
+#endif
                 const int skip_at = skip_base + nt * 32;
                 int* level_slot = &shared_level[wn * 128 + nt * 32 + col];
                 const int level = __hip_atomic_load(level_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -226,7 +258,13 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
                 const int last = list[nt][LIST - 1];
                 const int own = last == 0 ? 0 : (last >> kKeyShift) + 1;
                 const int need = own > level ? own : level;
+#ifdef SDRB_AP_EXP_PREFILTER_ONLY   // timing experiment: stop after the prefilter
+                if (m == 0x7fffffff) list[nt][0] = need;
+                continue;
+#endif
+                AP_STAMP(4, t_pre);
                 if (__builtin_amdgcn_ballot_w64(m >= need) == 0) continue;
+                const unsigned long long t_det = AP_NOW();
                 // per lane: which of its 64 parked slots qualify (slot order = ascending j) ...
                 uint32_t pass_lo = 0, pass_hi = 0;
 #pragma unroll
@@ -253,11 +291,25 @@ __global__ __launch_bounds__(256, 1) void k_allpairs_mfma(
                     }
                     list_insert<LIST>(list[nt], key);
                 }
+                AP_STAMP(5, t_det);
                 const int now = list[nt][LIST - 1];
                 if (now != last && (now >> kKeyShift) > level) atomicMax(level_slot, now >> kKeyShift);
             }
         }
+#else
+        {   // timing experiment only: keep every tile's product alive without the top-k work
+            int z = 0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) z += acc[mt][nt][0];
+            if (z == 0x7fffffff) list[0][0] = z;
+        }
+#endif
+        AP_STAMP(1, t_epi);
+        const unsigned long long t_bar = AP_NOW();
         __syncthreads();   // nobody may refill the parking buffer while a wave still walks its counts
+        AP_STAMP(2, t_bar);
     }
 
     // partial lists: [row i][split][wm*2 + half][LIST]
@@ -360,6 +412,9 @@ int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint
     // is the expensive part of the epilogue), each within the key range
     uint32_t splits = 1;
     while (splits < 8 && (uint64_t)((n_ipanels + 7) / 8 * 8) * splits < 256 && splits * 2 <= n_jpanels) splits *= 2;
+#ifdef SDRB_AP_FORCE_SPLITS   // tuning experiments only
+    splits = SDRB_AP_FORCE_SPLITS;
+#endif
     uint32_t pps = (n_jpanels + splits - 1) / splits;
     while ((uint64_t)pps * kPanel > kMaxSplitRows) {
         splits *= 2;
@@ -411,3 +466,13 @@ int launch_allpairs_mfma(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, i
 
 }  // namespace sdrb
 
+#ifdef SDRB_AP_EXP_STAMPS
+extern "C" int sdrb_debug_read_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sdrb::g_ap_stamps), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sdrb::g_ap_stamps), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
