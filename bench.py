@@ -378,6 +378,39 @@ def secondary_configs(dev) -> dict:
     same = np.array_equal(results["bitslice"][0], results["mfma"][0]) and np.array_equal(results["bitslice"][1], results["mfma"][1])
     out["c5_allpairs_bitslice"]["parity"] = out["c5_allpairs_bitslice"]["parity"] and bool(same)
     out["c5_allpairs_mfma"]["parity"] = out["c5_allpairs_mfma"]["parity"] and bool(same)
+    del a, b, results
+    torch.cuda.empty_cache()
+
+    # the headline shape with payloads: UnitData ands (product + relevance filter per match) and ArithData dot
+    # products, 4096 x 1 Mi rows, 2048/40; the oracle checks 8 queries x 256 rows
+    nq, nd = 4096, 1 << 20
+    qi, dj = np.sort(rng.choice(nq, 8, replace=False)), np.sort(rng.choice(nd, 256, replace=False))
+
+    def rows_with(csr, rows, vals):
+        off, ids, _ = _gather_rows(csr[0], csr[1], rows)
+        return off, ids, np.concatenate([vals[int(csr[0][r]):int(csr[0][r + 1])] for r in rows])
+
+    out_buf = torch.empty((nq, nd), dtype=torch.int32, device=dev)
+    d_csr = sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE, True)
+    q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE, True)
+    d, q = SDRBatch.from_csr(*d_csr, width=WIDTH), SDRBatch.from_csr(*q_csr, width=WIDTH)
+    ms, _ = _timed(lambda: q.ands(d, out=out_buf), reps=3)
+    want = oracle.port().size_op(oracle.AND, oracle.Batch(*rows_with(q_csr, qi, q_csr[2])), oracle.Batch(*rows_with(d_csr, dj, d_csr[2])))
+    got = out_buf[torch.as_tensor(qi, device=dev)][:, torch.as_tensor(dj, device=dev)].cpu().numpy().view(np.uint32)
+    nbytes = (nd + nq) * (8 * ACTIVE + 4) + nq * nd * 4
+    out["unit_ands_4096"] = line(ms, nbytes, bool(np.array_equal(got, want)),
+                                 workload=f"ands: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, UnitData on both sides")
+    del d, q
+    q_val = rng.standard_normal(q_csr[1].size).astype(np.float32)
+    d_val = rng.standard_normal(d_csr[1].size).astype(np.float32)
+    d = SDRBatch.from_csr(d_csr[0], d_csr[1], d_val, width=WIDTH, kind="arith")
+    q = SDRBatch.from_csr(q_csr[0], q_csr[1], q_val, width=WIDTH, kind="arith")
+    out_f = out_buf.view(torch.float32)
+    ms, _ = _timed(lambda: q.inner(d, out=out_f), reps=3)
+    want = oracle.port().inner(oracle.Batch(*rows_with(q_csr, qi, q_val), arith=True), oracle.Batch(*rows_with(d_csr, dj, d_val), arith=True))
+    got = out_f[torch.as_tensor(qi, device=dev)][:, torch.as_tensor(dj, device=dev)].cpu().numpy().view(np.uint32)
+    out["inner_4096"] = line(ms, nbytes, bool(np.array_equal(got, want.view(np.uint32))),
+                             workload=f"inner (sparse dot products): {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, ArithData<float>")
     return out
 
 

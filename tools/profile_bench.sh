@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-secondary"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --steps 20 --warmup 3 > $O/kt.log 2>&1 || { echo kt failed; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" \

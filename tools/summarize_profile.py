@@ -20,12 +20,19 @@ KERNEL = "k_size_bitslice"
 
 
 def counters(path_glob, kernel_substr):
-    """{counter: [value per dispatch]} for dispatches whose kernel name contains the substring."""
-    out = defaultdict(list)
+    """{counter: [value per dispatch]} for dispatches whose kernel name contains the substring; when the run holds
+    launches of several sizes (the bench also times smaller configurations) only those with the largest grid -- the
+    headline shape -- are kept."""
+    rows = []
     for f in glob.glob(path_glob):
         for row in csv.DictReader(open(f)):
             if kernel_substr in row["Kernel_Name"]:
-                out[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                rows.append(row)
+    biggest = max((int(r["Grid_Size"]) for r in rows), default=0)
+    out = defaultdict(list)
+    for row in rows:
+        if int(row["Grid_Size"]) == biggest:
+            out[row["Counter_Name"]].append(float(row["Counter_Value"]))
     return out
 
 
@@ -51,6 +58,16 @@ def main():
             w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
     main_row = next(r for r in rows if KERNEL in r["Name"])
     avg_ns = float(main_row["AverageNs"])
+    # the stats row averages every launch of the kernel; the trace tells the headline-shaped launches apart
+    trace = glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv"))
+    if trace:
+        t_rows = [r for r in csv.DictReader(open(trace[0])) if KERNEL in r["Kernel_Name"]]
+        if t_rows:
+            size = lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])   # noqa: E731
+            biggest = max(size(r) for r in t_rows)
+            durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in t_rows if size(r) == biggest]
+            avg_ns = sum(durs) / len(durs)
+            main_row = dict(main_row, Calls=str(len(durs)))
 
     pmc = {}
     for d in glob.glob(os.path.join(src, "pmc_*")):
