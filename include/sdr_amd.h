@@ -20,7 +20,12 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is
  *    enqueued asynchronously unless a function says it synchronises.
  *  - Device pointers passed in (out buffers, offsets) must live on the batch's device.
- *  - Handles are thread-compatible: use one handle from one thread at a time.
+ *  - Handles are thread-compatible: one thread at a time may upload into a handle; any number of threads may
+ *    read it (pass it to the operations below) at once.
+ *  - Scratch memory is kept per (device, stream): calls on different streams, from one thread or several, run
+ *    concurrently and never share a table (sdrb_size_op_static is the exception, see there).  Forms of a batch
+ *    that the library derives and caches in the handle (bit planes, byte matrix) are built on the stream of the
+ *    first call that needs them; calls on other streams wait for that build through an event.
  */
 #ifndef SDR_AMD_H
 #define SDR_AMD_H
@@ -124,8 +129,10 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
 /*
  * Batches with 64-bit ids (the reference's SDRElem<long, ...>, fuzzed in src/fuzz.cpp:413-423).
  * Such a batch has no declared width and EmptyData or UnitData payloads; it is taken by sdrb_size_op,
- * sdrb_elem_op_count and sdrb_elem_op_fill64 (both batches of a call must hold ids of the same
- * width; the per-pair merge kernels serve them), and refused by everything else.
+ * sdrb_equal, sdrb_elem_op_count and sdrb_elem_op_fill64 (both batches of a call must hold ids of the same
+ * width; the per-pair merge kernels serve them).  When every id of a batch fits 32 bits the handle also keeps the
+ * ids narrowed; two such batches are served by the kernels of the 32-bit path (ids of results widened back), and
+ * sdrb_allpairs_topk takes them as well.  Everything else refuses 64-bit batches.
  */
 int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out);
 int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,

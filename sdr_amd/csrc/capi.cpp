@@ -73,8 +73,22 @@ void reap_retired(int device) {
     (void)hipGetLastError();   // hipErrorNotReady of a pending event is not an error
 }
 
+void drop_derived(sdrb_batch* b);
+
+// the narrowed twin of a batch of 64-bit ids (a view: it owns nothing but its derived forms)
+void drop_narrow(sdrb_batch* b) {
+    if (b->narrow) {
+        drop_derived(b->narrow);
+        delete b->narrow;
+        b->narrow = nullptr;
+    }
+    if (b->d_narrow_ids) (void)hipFree(b->d_narrow_ids);
+    b->d_narrow_ids = nullptr;
+}
+
 // Data derived from the rows (bit planes, dense byte matrix) dies with the content it was built from.
 void drop_derived(sdrb_batch* b) {
+    drop_narrow(b);
     if (b->d_bitplanes) (void)hipFree(b->d_bitplanes);
     if (b->d_dense8) (void)hipFree(b->d_dense8);
     b->d_bitplanes = nullptr;
@@ -205,6 +219,16 @@ int check_ids32(const sdrb_batch* a, const sdrb_batch* b, const char* what) {
     return SDRB_OK;
 }
 
+// Two batches of 64-bit ids that both keep a 32-bit twin are served through the twins (every table kernel applies);
+// SDRB_FLAG_FORCE_MERGE keeps the call on the 64-bit merge kernels.
+bool narrow_pair(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags) {
+    if (!a || !b || a->id_bits != 64 || b->id_bits != 64 || !a->narrow || !b->narrow) return false;
+    if (flags & SDRB_FLAG_FORCE_MERGE) return false;
+    a = a->narrow;
+    b = b->narrow;
+    return true;
+}
+
 // Which payload pairings the set algebra takes: EmptyData and UnitData in any mix (UnitData.hpp:43-46),
 // ArithData<float> with itself or with EmptyData (ArithData.hpp:37-83); ArithData defines no xor (:110-114).
 int check_set_algebra_kinds(const sdrb_batch* a, const sdrb_batch* b, int op) {
@@ -229,6 +253,8 @@ struct IdView {
         v.data_kind = SDRB_DATA_EMPTY;
         v.d_data = nullptr;
         v.owns_storage = false;
+        v.narrow = nullptr;          // the twin of a batch of 64-bit ids keeps its payload kind: not this view's twin
+        v.d_narrow_ids = nullptr;
     }
     ~IdView() {
         // only what was built through THIS view is handed back (two views of one batch may be alive at once)
@@ -377,6 +403,7 @@ static int sdrb_batch_upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, cons
     }
     std::vector<uint32_t> off32(n_rows + 1);
     uint32_t max_len = 0;
+    int64_t lowest = INT64_MAX, highest = INT64_MIN;
     for (uint64_t r = 0; r < n_rows; ++r) {
         const uint64_t lo = row_offsets[r], hi = row_offsets[r + 1];
         if (hi < lo || hi > nnz) {
@@ -390,6 +417,10 @@ static int sdrb_batch_upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, cons
                 set_error("row %llu is not strictly ascending", (unsigned long long)r);
                 return SDRB_ERR_NOT_ASCENDING;
             }
+        if (hi > lo) {   // rows ascend: their ends are their extremes
+            if (ids[lo] < lowest) lowest = ids[lo];
+            if (ids[hi - 1] > highest) highest = ids[hi - 1];
+        }
     }
     off32[n_rows] = (uint32_t)nnz;
     if (payload)
@@ -415,6 +446,31 @@ static int sdrb_batch_upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, cons
     batch->max_row_len = max_len;
     batch->min_id = 0;
     batch->max_id = -1;
+    // ids that all fit 32 bits (the reference's SDRElem<long> rows usually do): keep them narrowed as well
+    if (nnz == 0 || (lowest >= INT32_MIN && highest < INT32_MAX)) {
+        std::vector<int32_t> small(nnz);
+        for (uint64_t k = 0; k < nnz; ++k) small[k] = (int32_t)ids[k];
+        if (nnz) {
+            SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_narrow_ids), nnz * sizeof(int32_t)));
+            SDRB_HIP(hipMemcpyAsync(batch->d_narrow_ids, small.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SDRB_HIP(hipStreamSynchronize(s));
+        }
+        sdrb_batch* twin = new sdrb_batch;
+        twin->device = batch->device;
+        twin->data_kind = batch->data_kind;
+        twin->id_bits = 32;
+        twin->width = (nnz && lowest >= 0) ? (int32_t)(highest + 1) : 0;
+        twin->n_rows = n_rows;
+        twin->nnz = nnz;
+        twin->max_row_len = max_len;
+        twin->min_id = nnz ? (int32_t)lowest : 0;
+        twin->max_id = nnz ? (int32_t)highest : -1;
+        twin->d_offsets = batch->d_offsets;
+        twin->d_ids = batch->d_narrow_ids;
+        twin->d_data = batch->d_data;
+        twin->owns_storage = false;
+        batch->narrow = twin;
+    }
     return SDRB_OK;
 }
 
@@ -707,6 +763,7 @@ int sdrb_batch_destroy(sdrb_batch* batch) {
 
 int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                  uint64_t ld_out, void* stream) {
+    narrow_pair(a, b, flags);
     int rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
     if (rc != SDRB_OK) return rc;
@@ -821,6 +878,7 @@ int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
 }
 
 int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream) {
+    narrow_pair(a, b, flags);
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
     if (rc != SDRB_OK) return rc;
@@ -1028,6 +1086,7 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
 
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
+    narrow_pair(a, b, 0);
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_allpairs_topk");
     if (rc != SDRB_OK) return rc;
@@ -1100,6 +1159,7 @@ uint64_t elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                        uint32_t* out_offsets, uint64_t* total, void* stream) {
+    narrow_pair(a, b, flags);
     uint64_t pairs = 0;
     int rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
     if (rc != SDRB_OK) return rc;
@@ -1135,6 +1195,29 @@ int sdrb_elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 namespace {
 int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, const uint32_t* out_offsets,
                      void* out_ids_any, int want_bits, float* out_data, void* stream) {
+    if (want_bits == 64 && out_offsets && out_ids_any) {
+        const sdrb_batch *na = a, *nb = b;
+        if (narrow_pair(na, nb, flags)) {
+            // both batches keep 32-bit twins: fill through the 32-bit kernels into scratch, then widen the ids
+            const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+            const uint64_t pairs = rowwise ? nb->n_rows : na->n_rows * nb->n_rows;
+            DeviceGuard guard(nb->device);
+            if (!guard.ok) {
+                set_error("hipSetDevice(%d) failed", nb->device);
+                return SDRB_ERR_HIP;
+            }
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            uint32_t total = 0;
+            SDRB_HIP(hipMemcpyAsync(&total, out_offsets + pairs, sizeof total, hipMemcpyDeviceToHost, s));
+            SDRB_HIP(hipStreamSynchronize(s));
+            if (total == 0) return SDRB_OK;
+            int32_t* tmp = static_cast<int32_t*>(workspace(nb->device, s, 11, (size_t)total * sizeof(int32_t)));
+            if (!tmp) return SDRB_ERR_HIP;
+            const int rc32 = elem_op_fill_any(na, nb, op, flags, out_offsets, tmp, 32, out_data, stream);
+            if (rc32 != SDRB_OK) return rc32;
+            return launch_widen_ids(tmp, static_cast<int64_t*>(out_ids_any), total, s);
+        }
+    }
     int rc = check_pair(a, b, op);
     if (rc == SDRB_OK && a->id_bits != want_bits) {
         set_error("these batches hold %d-bit ids: use %s", a->id_bits,

@@ -16,7 +16,7 @@ struct sdrb_batch {
     int device = 0;
     int32_t width = 0;     // 0 = undeclared
     int data_kind = SDRB_DATA_EMPTY;
-    int id_bits = 32;      // 64: d_ids points at int64 ids (merge kernels only; min_id/max_id unused)
+    int id_bits = 32;      // 64: d_ids points at int64 ids (min_id/max_id unused); see `narrow`
     uint64_t n_rows = 0;
     uint64_t nnz = 0;
     uint32_t max_row_len = 0;
@@ -33,6 +33,11 @@ struct sdrb_batch {
     // build, and a call on any other stream waits for it before its kernels read the form.
     hipEvent_t bitplanes_ready = nullptr, dense_ready = nullptr;
     hipStream_t bitplanes_stream = nullptr, dense_stream = nullptr;
+    // A batch of 64-bit ids whose ids all fit 32 bits also keeps them narrowed: `narrow` is a 32-bit batch that
+    // views this batch's offsets and payloads and owns only d_narrow_ids (declared width = largest id + 1 when no
+    // id is negative), so that two such batches are served by every kernel the 32-bit path has.
+    sdrb_batch* narrow = nullptr;
+    int32_t* d_narrow_ids = nullptr;
 };
 
 namespace sdrb {
@@ -123,6 +128,8 @@ int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64
                  hipStream_t stream);
 
 // elem_ops.hip --------------------------------------------------------------------
+// out[k] = in[k] widened to 64 bits (results of the 32-bit kernels for batches of 64-bit ids)
+int launch_widen_ids(const int32_t* in, int64_t* out, uint64_t n, hipStream_t stream);
 // In-place exclusive prefix sum of data[0..n) in one pass; entries at index >= n_valid count as zero (so a
 // scan over n = pairs + 1, n_valid = pairs leaves the total in data[pairs] without clearing it first).
 // Offsets are kept modulo 2^32; the exact 64-bit sum goes to *total_dev (device memory, may be null).

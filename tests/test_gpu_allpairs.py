@@ -179,3 +179,22 @@ def test_sharded_query_topk_full_size_one_rank_with_collectives():
         assert np.array_equal(c2.cpu().numpy(), want_c) and np.array_equal(r2.cpu().numpy(), want_r)
     finally:
         dist.destroy_process_group()
+
+
+def test_candidate_row_limits_are_refused_before_any_work():
+    """The merge of the partial top-k lists holds 512 keys a row: 8 splits of the matrix-core kernel (4 192 256
+    candidate rows) or 32 of the bit-sliced one (16 775 168).  One candidate row more than the first limit: the
+    matrix-core kernel refuses up front, the bit-sliced kernel still serves the call."""
+    from sdr_amd import SDRBatch, SdrbError
+    nb = 4_192_256 + 1
+    ids = (np.arange(nb, dtype=np.int64) % 8).astype(np.int32)          # one id a row, ids 0..7 in turn
+    off = np.arange(nb + 1, dtype=np.uint64)
+    b = SDRBatch.from_csr(off, ids, None, width=8)
+    a = SDRBatch.from_csr(np.array([0, 1, 3], np.uint64), np.array([5, 0, 7], np.int32), None, width=8)
+    with pytest.raises(SdrbError) as e:
+        a.allpairs_topk(b, 4, algo="mfma")
+    assert e.value.code == -5 and "4 192 256" in str(e.value)
+    counts, rows = a.allpairs_topk(b, 4)
+    assert counts.cpu().numpy().tolist() == [[1, 1, 1, 1], [1, 1, 1, 1]]
+    # ties go to the lower row: rows holding id 5, and rows holding id 0 or 7
+    assert rows.cpu().numpy().tolist() == [[5, 13, 21, 29], [0, 7, 8, 15]]

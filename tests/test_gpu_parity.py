@@ -620,3 +620,48 @@ def test_lanemerge_fill_signed_ids_chunks_of_a_and_sentinel():
     with pytest.raises(sdr_amd.SdrbError):
         gpu_elems(OR, dtop, da, algo="lanemerge")
     assert_elems_equal(gpu_elems(OR, dtop, da), oracle.port().elem_op(OR, top, a))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_64_bit_batches_whose_ids_fit_32_bits_take_the_fast_kernels(name):
+    """`long` ids that happen to be small (what the reference's own fuzzer feeds SDRElem<long>, src/fuzz.cpp:413-423):
+    the batch keeps a narrowed twin, so every kernel of the 32-bit path serves it and the ids come back as int64;
+    results equal the oracle's and those of the 64-bit merge kernels; a partner with huge ids keeps the pair there."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(31 + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, 40, 2048, 40, tu))
+    a = Batch(*util.ragged_rows(rng, 300, 2048, 40, au))
+    t64 = SDRBatch.from_csr(t.off, t.ids.astype(np.int64), t.data)
+    a64 = SDRBatch.from_csr(a.off, a.ids.astype(np.int64), a.data)
+    assert t64.id_bits == 64 and a64.id_bits == 64
+    for op in range(4):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(gpu_sizes(op, t64, a64), want), op
+        assert np.array_equal(gpu_sizes(op, t64, a64, algo="merge"), want), op
+        assert np.array_equal(gpu_sizes(op, t64, a64, swap=True), oracle.port().size_op(op, a, t).T), op
+        w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+        for algo in (None, "merge"):
+            off, ids, data = gpu_elems(op, t64, a64, algo=algo)
+            assert ids.dtype == np.int64
+            assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids.astype(np.int64)), (op, algo)
+            assert (data is None) == (w_data is None) and (data is None or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))
+    # all-pairs top-k, refused for 64-bit ids in general, runs on the twins
+    c64, r64 = a64.allpairs_topk(a64, 4, exclude_offset=0)
+    a32 = dev(Batch(a.off, a.ids, None), 2048)
+    c32, r32 = a32.allpairs_topk(a32, 4, exclude_offset=0)
+    assert np.array_equal(c64.cpu().numpy(), c32.cpu().numpy()) and np.array_equal(r64.cpu().numpy(), r32.cpu().numpy())
+    # one side with ids beyond 32 bits: no twin there, the pair stays on the merge kernels and is still right
+    shift = np.int64(1) << 40
+    far = SDRBatch.from_csr(a.off, a.ids.astype(np.int64) + shift, a.data)
+    assert np.array_equal(gpu_sizes(OR, t64, far), oracle.port().size_op(OR, t, Batch(a.off, a.ids + 5000, a.data)))
+    # negative ids: a twin without a declared width
+    neg_t = Batch(*util.ragged_rows(rng, 9, 300, 20, tu, lo=-150))
+    neg_a = Batch(*util.ragged_rows(rng, 70, 300, 20, au, lo=-150))
+    n_t = SDRBatch.from_csr(neg_t.off, neg_t.ids.astype(np.int64), neg_t.data)
+    n_a = SDRBatch.from_csr(neg_a.off, neg_a.ids.astype(np.int64), neg_a.data)
+    for op in range(4):
+        assert np.array_equal(gpu_sizes(op, n_t, n_a), oracle.port().size_op(op, neg_t, neg_a)), op
+        off, ids, data = gpu_elems(op, n_t, n_a)
+        w_off, w_ids, w_data = oracle.port().elem_op(op, neg_t, neg_a)
+        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids.astype(np.int64)), op
