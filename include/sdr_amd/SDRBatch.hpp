@@ -272,6 +272,26 @@ class Elements {
     }
 };
 
+// An element-op result too long for one CSR with 32-bit offsets (more than 2^32-1 elements): rows
+// starts[c] .. starts[c+1] of A are held by chunks[c], an Elements over those rows of A and all rows of B.
+class ChunkedElements {
+ public:
+    size_t na = 0, nb = 0;
+    std::vector<size_t> starts;
+    std::vector<Elements> chunks;
+    uint64_t total() const {
+        uint64_t t = 0;
+        for (const Elements& e : chunks) t += e.total;
+        return t;
+    }
+    // which chunk holds row i of A, and which of the chunk's rows it is
+    std::pair<size_t, size_t> locate(size_t i) const {
+        size_t c = 0;
+        while (c + 1 < chunks.size() && starts[c + 1] <= i) ++c;
+        return {c, i - starts[c]};
+    }
+};
+
 class SDRBatch {
  public:
     SDRBatch(int device, int32_t width, int data_kind, int id_bits = 32)
@@ -369,6 +389,64 @@ class SDRBatch {
     Elements ore(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_OR, db, flags, stream); }
     Elements xore(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_XOR, db, flags, stream); }
     Elements rme(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_RM, db, flags, stream); }
+
+    // The same four results when they may exceed 2^32-1 elements (e.g. 64 rows of 328 ids in union with 128 Ki
+    // such rows): the rows of *this are cut into consecutive ranges whose results fit, one CSR each.  op is
+    // SDRB_OP_AND / OR / XOR / RM; `limit` (elements per CSR) exists for tests.  Batches of 32-bit ids.
+    ChunkedElements elem_op_chunked(int op, const SDRBatch& db, unsigned flags = 0, void* stream = nullptr,
+                                    uint64_t limit = 0xFFFFFFFFull) const {
+        if (id_bits_ != 32 || db.id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "chunked results serve batches of 32-bit ids");
+        if (flags & SDRB_FLAG_ROWWISE) throw Error(SDRB_ERR_INVALID_ARG, "row-wise results never need chunks");
+        ChunkedElements out;
+        out.na = n_rows_;
+        out.nb = db.n_rows_;
+        const uint32_t* d_off = nullptr;
+        const int32_t* d_ids = nullptr;
+        const float* d_data = nullptr;
+        check(sdrb_batch_device_ptrs(h_, &d_off, &d_ids, &d_data));
+        std::vector<uint32_t> off(n_rows_ + 1);
+        check(sdrb_memcpy_d2h(device_, off.data(), d_off, off.size() * sizeof(uint32_t), stream));
+        uint64_t b_nnz = 0;
+        check(sdrb_batch_info(db.h_, nullptr, nullptr, &b_nnz, nullptr, nullptr, nullptr));
+        // the most elements row i of *this can contribute (the bound sdrb_elem_op_bound uses, row by row)
+        const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+        auto row_bound = [&](size_t i) -> uint64_t {
+            const uint64_t from_a = (uint64_t)(off[i + 1] - off[i]) * db.n_rows_;
+            if (op == SDRB_OP_AND) return from_a < b_nnz ? from_a : b_nnz;
+            if (op == SDRB_OP_RM) return swap ? b_nnz : from_a;
+            return from_a + b_nnz;
+        };
+        out.starts.push_back(0);
+        uint64_t acc = 0;
+        for (size_t i = 0; i < n_rows_; ++i) {
+            const uint64_t r = row_bound(i);
+            if (r > limit) throw Error(SDRB_ERR_OVERFLOW, "one row against all rows of the other batch exceeds the limit: split the other batch");
+            if (acc + r > limit) {
+                out.starts.push_back(i);
+                acc = 0;
+            }
+            acc += r;
+        }
+        out.starts.push_back(n_rows_);
+        uint32_t max_len = 0;
+        int32_t width = 0, lo_id = 0, hi_id = -1;
+        check(sdrb_batch_info(h_, nullptr, nullptr, nullptr, &width, nullptr, &max_len));
+        check(sdrb_batch_id_span(h_, &lo_id, &hi_id));
+        for (size_t c = 0; c + 1 < out.starts.size(); ++c) {
+            const size_t i0 = out.starts[c], i1 = out.starts[c + 1];
+            std::vector<uint32_t> sub(off.begin() + i0, off.begin() + i1 + 1);
+            for (uint32_t& o : sub) o -= off[i0];
+            detail::DeviceBuffer sub_off(device_, sub.size() * sizeof(uint32_t));
+            check(sdrb_memcpy_h2d(device_, sub_off.ptr, sub.data(), sub.size() * sizeof(uint32_t), stream));
+            SDRBatch part(device_, width, kind_);
+            check(sdrb_batch_adopt_device_csr(part.h_, i1 - i0, off[i1] - off[i0], static_cast<const uint32_t*>(sub_off.ptr),
+                                              d_ids + off[i0], d_data ? d_data + off[i0] : nullptr, max_len, lo_id, hi_id));
+            part.n_rows_ = i1 - i0;
+            out.chunks.push_back(part.elem_op(op, db, flags, stream));
+            check(sdrb_stream_sync(device_, stream));   // the view's offsets are released at the end of this turn
+        }
+        return out;
+    }
 
     // Row-wise forms for two batches of equal length: result j = (*this)[j].op(arg[j]).
     // op is SDRB_OP_AND / OR / XOR / RM; sizes come as a 1 x n table, elements as a CSR with one result per row.

@@ -75,6 +75,28 @@ int run(const char* name, std::mt19937& rng, int width, int32_t declared_width) 
             REQUIRE(sdr_amd::Elements::unpack<R>(h_xor, ds.size(), i, j) == qs[i].xore(ds[j]));
             REQUIRE(sdr_amd::Elements::unpack<R>(h_rm, ds.size(), i, j) == qs[i].rme(ds[j]));
         }
+    // results in chunks over the rows of `this` (what a result of more than 2^32-1 elements comes back as; the limit
+    // is lowered so that these small batches need several chunks): every pair equals the reference's call
+    if constexpr (sizeof(typename A::value_type::id_type) <= 4 && sizeof(typename B::value_type::id_type) <= 4) {
+        const int ops[4] = {SDRB_OP_AND, SDRB_OP_OR, SDRB_OP_XOR, SDRB_OP_RM};
+        for (int op : ops) {
+            auto parts = q.elem_op_chunked(op, d, 0, nullptr, /*limit*/ 60000);
+            REQUIRE(parts.chunks.size() > 1);
+            REQUIRE(parts.starts.front() == 0 && parts.starts.back() == qs.size());
+            std::vector<sdr_amd::Elements::Host> hosts;
+            for (auto& c : parts.chunks) hosts.push_back(c.to_host());
+            for (size_t i = 0; i < qs.size(); ++i) {
+                const auto where = parts.locate(i);
+                for (size_t j = 0; j < ds.size(); j += 7) {
+                    const R got = sdr_amd::Elements::unpack<R>(hosts[where.first], ds.size(), where.second, j);
+                    if (op == SDRB_OP_AND) REQUIRE(got == qs[i].ande(ds[j]));
+                    else if (op == SDRB_OP_OR) REQUIRE(got == qs[i].ore(ds[j]));
+                    else if (op == SDRB_OP_XOR) REQUIRE(got == qs[i].xore(ds[j]));
+                    else REQUIRE(got == qs[i].rme(ds[j]));
+                }
+            }
+        }
+    }
     std::printf("ok %-28s %ld checks so far\n", name, g_checks);
     return 0;
 }
