@@ -817,12 +817,10 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_UNSUPPORTED;
     }
     if (flags & SDRB_FLAG_FORCE_SPARSE) {
-        if (!size_lane_rows_applicable(a, b, op, swap, true)) {
-            set_error("lane-per-row match kernel requested but not applicable (payload-dependent op, width <= 4096, "
-                      "rows of b <= 64 ids, rows of a <= 128 ids)");
-            return SDRB_ERR_UNSUPPORTED;
-        }
-        return launch_size_lane_rows(a, b, op, swap, out, ld_out, s);
+        if (size_lane_rows_applicable(a, b, op, swap, true)) return launch_size_lane_rows(a, b, op, swap, out, ld_out, s);
+        set_error("lane-per-row match kernel requested but not applicable (payload-dependent op, width <= 4096, "
+                  "rows of b <= 64 ids, rows of a <= 128 ids)");
+        return SDRB_ERR_UNSUPPORTED;
     }
     if (flags & SDRB_FLAG_FORCE_POPCOUNT) {
         if (a->id_bits != 32 || !id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
