@@ -151,6 +151,20 @@ class VisitResult:
         return (self.offsets.cpu().numpy().view(np.uint32).astype(np.uint64),
                 self.this_pos.cpu().numpy().view(np.uint32), self.arg_pos.cpu().numpy().view(np.uint32))
 
+    def window(self, this_lo: int = 0, this_hi: int = 0xFFFFFFFF, arg_lo: int = 0, arg_hi: int = 0xFFFFFFFF) -> "VisitResult":
+        """The calls of the reference's sub-range ``andv(arg, visitor, this_pos, this_end, arg_pos, arg_end)``
+        (SDR.hpp:196-202) when every pair is given the same windows: the records whose position in ``this`` lies in
+        ``[this_lo, this_hi)`` and whose position in ``arg`` lies in ``[arg_lo, arg_hi)`` -- two sorted sequences meet
+        in a common id inside both windows exactly where the whole rows do.  Positions stay those of the whole rows."""
+        import torch
+        tp = self.this_pos.to(torch.int64) & 0xFFFFFFFF
+        ap = self.arg_pos.to(torch.int64) & 0xFFFFFFFF
+        keep = (tp >= this_lo) & (tp < this_hi) & (ap >= arg_lo) & (ap < arg_hi)
+        kept_upto = torch.cat([torch.zeros(1, dtype=torch.int64, device=keep.device), torch.cumsum(keep, 0)])
+        off = kept_upto[self.offsets.to(torch.int64) & 0xFFFFFFFF]
+        off32 = torch.where(off >= 2 ** 31, off - 2 ** 32, off).to(torch.int32)
+        return VisitResult(self.na, self.nb, off32, self.this_pos[keep], self.arg_pos[keep], int(kept_upto[-1]))
+
 
 POS_NONE = 0xFFFFFFFF
 

@@ -153,3 +153,26 @@ def test_empty_rows_and_batches():
         some.andv(SDRBatch.from_rows([[1]], width=64), rowwise=True)
     with pytest.raises(sdr_amd.SdrbError):          # batches of different id widths
         some.andv(SDRBatch.from_csr(np.array([0, 1], np.uint64), np.array([1], np.int64), None))
+
+
+def test_andv_over_sub_ranges():
+    """andv on sub-ranges of both rows (SDR.hpp:196-202) = andv of the rows cut to those ranges, positions counted
+    from the start of the whole rows; here every pair gets the same windows."""
+    rng = np.random.default_rng(77)
+    t_off, t_ids, _ = util.ragged_rows(rng, 9, 300, 60)
+    a_off, a_ids, _ = util.ragged_rows(rng, 40, 300, 60)
+    t, a = SDRBatch.from_csr(t_off, t_ids, width=300), SDRBatch.from_csr(a_off, a_ids, width=300)
+    t_lo, t_hi, a_lo, a_hi = 5, 33, 2, 41
+
+    def cut(off, ids, lo, hi):
+        rows = [ids[int(off[r]):int(off[r + 1])][lo:hi] for r in range(len(off) - 1)]
+        new_off = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint64)
+        return new_off, (np.concatenate(rows) if rows else np.zeros(0, np.int32)).astype(np.int32)
+
+    ct, ca = SDRBatch.from_csr(*cut(t_off, t_ids, t_lo, t_hi), width=300), SDRBatch.from_csr(*cut(a_off, a_ids, a_lo, a_hi), width=300)
+    got = t.andv(a).window(t_lo, t_hi, a_lo, a_hi)
+    want = ct.andv(ca)
+    g_off, g_tp, g_ap = got.to_host()
+    w_off, w_tp, w_ap = want.to_host()
+    assert got.total == want.total and np.array_equal(g_off, w_off)
+    assert np.array_equal(g_tp, w_tp + t_lo) and np.array_equal(g_ap, w_ap + a_lo)
