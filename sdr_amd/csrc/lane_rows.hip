@@ -326,10 +326,10 @@ bool shapes_fit(const sdrb_batch* a, const sdrb_batch* b) {
     return a->max_row_len <= (uint32_t)kMaxRowA && a->n_rows <= 0x7FFFFFE0ull;
 }
 
-// a match costs several times a dense table's multiply-add or a bit-sliced count: only where most candidates
-// are misses (on average at most one row of a tile holds a given id)
-bool sparse_enough(const sdrb_batch* a, int wcap) {
-    return (uint64_t)kTile * a->nnz <= (uint64_t)a->n_rows * (uint64_t)wcap;
+// a match costs several times a dense table's multiply-add or a mask-table visit: only where most candidates are
+// misses -- on average at most `tenths`/10 rows of a 32-row tile hold a given id of the declared width
+bool sparse_enough(const sdrb_batch* a, const sdrb_batch* b, uint64_t tenths) {
+    return 10ull * kTile * a->nnz <= tenths * a->n_rows * (uint64_t)b->width;
 }
 
 // tables of A in scratch, grid and LDS size; `with_vals`: A's payloads are tabulated
@@ -349,8 +349,12 @@ int prepare(const sdrb_batch* a, const sdrb_batch* b, bool with_vals, hipStream_
     SDRB_HIP(hipGetLastError());
     g->tables = tables;
     g->lds = (size_t)g->tile_bytes + (size_t)kTile * kBlock * sizeof(uint32_t);
+    // Three blocks are resident per compute unit (768 in all).  A block walks every tile with its rows of B in
+    // registers, so one block per 256 rows of B is the cheapest cut; with fewer than four rounds of blocks the last,
+    // partly filled round would idle much of the chip, and the tiles are shared out over blockIdx.y instead (the
+    // rows of B are then fetched once per share, from L2).
     const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
-    uint32_t gy = gx >= 768 ? 1u : (768u + gx - 1) / gx;
+    uint32_t gy = gx >= 4u * 768u ? 1u : (4u * 768u + gx - 1) / gx;
     if (gy > g->ntiles) gy = g->ntiles;
     g->tiles_per_block = (g->ntiles + gy - 1) / gy;
     gy = (g->ntiles + g->tiles_per_block - 1) / g->tiles_per_block;
@@ -364,10 +368,10 @@ int prepare(const sdrb_batch* a, const sdrb_batch* b, bool with_vals, hipStream_
 // `forced`: whether the kernel can serve the batches at all; else whether it is also the faster choice
 bool inner_sparse_applicable(const sdrb_batch* a, const sdrb_batch* b, bool forced) {
     if (!shapes_fit(a, b)) return false;
-    const int wcap = b->width <= 2048 ? 2048 : 4096;
     // an id of A beyond the table would be dropped: fine for a match count, and for a dot product as well (it
-    // cannot match an id of B, all of which lie below B's width)
-    return forced || sparse_enough(a, wcap);
+    // cannot match an id of B, all of which lie below B's width).  Against the dense value table the match walk wins
+    // up to several rows of a tile per id (measured at 256/40: 5 rows per id, 1.7 against 2.3 ms).
+    return forced || sparse_enough(a, b, 60);
 }
 
 int launch_inner_sparse(const sdrb_batch* a, const sdrb_batch* b, float* out, uint64_t ld_out, hipStream_t stream) {
@@ -389,7 +393,10 @@ bool size_lane_rows_applicable(const sdrb_batch* a, const sdrb_batch* b, int op,
     if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) return false;
     const int math = pick_math(a, b, op, swap);
     if (math == kKeepAll || math == kDropAll) return false;          // ids alone decide: the bit-sliced kernel's case
-    return forced || (a->n_rows > 16 && sparse_enough(a, b->width <= 2048 ? 2048 : 4096));
+    // against the mask-table kernel: rows of B of at most 40 ids (longer rows leave a lane no registers for the tile
+    // in flight; measured at 4096/64: 1.67 against 1.03 ms) -- then it wins from 0.16 to 5 rows of a tile per id
+    // (1024 x 256 Ki rows of 40 ids at widths 4096 ... 256: 0.52 / 0.58, 0.65 / 0.81, 0.80 / 0.91, 1.03 / 1.09, 1.42 / 1.55 ms)
+    return forced || (a->n_rows > 16 && b->max_row_len <= 40 && sparse_enough(a, b, 50));
 }
 
 int launch_size_lane_rows(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out, uint64_t ld_out,
