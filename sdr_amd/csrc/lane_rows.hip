@@ -350,11 +350,14 @@ int prepare(const sdrb_batch* a, const sdrb_batch* b, bool with_vals, hipStream_
     g->tables = tables;
     g->lds = (size_t)g->tile_bytes + (size_t)kTile * kBlock * sizeof(uint32_t);
     // Three blocks are resident per compute unit (768 in all).  A block walks every tile with its rows of B in
-    // registers, so one block per 256 rows of B is the cheapest cut; with fewer than four rounds of blocks the last,
-    // partly filled round would idle much of the chip, and the tiles are shared out over blockIdx.y instead (the
-    // rows of B are then fetched once per share, from L2).
+    // registers, so one block per 256 rows of B is the cheapest cut; with fewer than eight rounds of blocks the last,
+    // partly filled round idles a noticeable part of the chip, and the tiles are shared out over blockIdx.y instead
+    // (the rows of B are then fetched once per share, from L2; 4096 x 1 Mi: 8.03 -> 7.77 ms with two shares).
     const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
-    uint32_t gy = gx >= 4u * 768u ? 1u : (4u * 768u + gx - 1) / gx;
+    uint32_t gy = gx >= 8u * 768u ? 1u : (8u * 768u + gx - 1) / gx;
+#ifdef SDRB_LR_GY   // tuning experiments only
+    gy = SDRB_LR_GY;
+#endif
     if (gy > g->ntiles) gy = g->ntiles;
     g->tiles_per_block = (g->ntiles + gy - 1) / gy;
     gy = (g->ntiles + g->tiles_per_block - 1) / g->tiles_per_block;
