@@ -355,9 +355,6 @@ int prepare(const sdrb_batch* a, const sdrb_batch* b, bool with_vals, hipStream_
     // (the rows of B are then fetched once per share, from L2; 4096 x 1 Mi: 8.03 -> 7.77 ms with two shares).
     const uint32_t gx = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
     uint32_t gy = gx >= 8u * 768u ? 1u : (8u * 768u + gx - 1) / gx;
-#ifdef SDRB_LR_GY   // tuning experiments only
-    gy = SDRB_LR_GY;
-#endif
     if (gy > g->ntiles) gy = g->ntiles;
     g->tiles_per_block = (g->ntiles + gy - 1) / gy;
     gy = (g->ntiles + g->tiles_per_block - 1) / g->tiles_per_block;
