@@ -314,6 +314,19 @@ int sdrb_elem_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
                  int32_t* out_ids, float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream);
 
 /*
+ * ande (SDR.hpp:999-1025) of a FEW rows of `a` -- 1 to 32: one query against a database is the reference's own use
+ * (README.md:63-90) -- with every row of `b`, in one call that never waits for the GPU and never passes over the
+ * per-pair offsets between counting and filling.  At SDR densities such a result is sparse (0.78 elements a pair at
+ * 2048/40), so the caller sizes out_ids (and out_data when `this` carries payloads) by an ESTIMATE: `capacity`
+ * elements.  out_offsets[na*nb + 1] always receives the complete exclusive offsets and *total_dev (device memory,
+ * required) the exact element total; elements at positions >= capacity are not written -- a caller who reads a total
+ * above its capacity calls again with room.  Needs a declared width <= 4096 on `b`, rows of `b` of at most 64 ids,
+ * EmptyData or UnitData payloads, 32-bit ids.  Flags: SDRB_FLAG_SWAP.
+ */
+int sdrb_ande_few(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out_offsets, int32_t* out_ids,
+                  float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream);
+
+/*
  * Batched visitors: what the reference's extension API hands to its callbacks (README.md:133-155), for
  * every pair, as arrays -- the raw material for operations the library does not have.
  *   SDRB_VISIT_AND -> andv (SDR.hpp:186-194, 958-997): one record per id match, ascending by id:

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "sdrb_elem_op_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
     "sdrb_elem_op_bound": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _u64p]),
     "sdrb_elem_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "sdrb_ande_few": (C.c_int, [_vp, _vp, C.c_uint, _vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "sdrb_equal": (C.c_int, [_vp, _vp, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_visit_count": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _u64p, _vp]),
     "sdrb_visit_fill": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),

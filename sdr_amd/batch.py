@@ -63,7 +63,7 @@ class ElemResult:
     device: ``total``, ``ids`` and ``data`` read that count (one stream synchronisation) the first time they are
     asked for; ``offsets`` and the untrimmed ``ids_buffer`` / ``data_buffer`` never wait."""
 
-    def __init__(self, na, nb, offsets, ids, data, total=None, total_dev=None):
+    def __init__(self, na, nb, offsets, ids, data, total=None, total_dev=None, refill=None):
         self.na = na
         self.nb = nb
         self.offsets = offsets            # torch.int32 [na*nb + 1] (values are uint32)
@@ -71,11 +71,15 @@ class ElemResult:
         self.data_buffer = data           # torch.float32 [>= total] or None
         self._total = total
         self._total_dev = total_dev       # torch.int64 [1] on the device, or None
+        self._refill = refill             # buffers sized by an estimate: called with the exact total if they were too small
 
     @property
     def total(self) -> int:
         if self._total is None:
             self._total = int(self._total_dev.item())
+            if self._refill is not None and self._total > self.ids_buffer.numel():
+                self.offsets, self.ids_buffer, self.data_buffer = self._refill(self._total)
+            self._refill = None
         return self._total
 
     @property
@@ -478,6 +482,33 @@ class SDRBatch:
             chunked = self._elem_op_chunked(op, other, swap, stream, algo, flags)
             if chunked is not None:
                 return chunked
+        few = other if swap else self          # which side holds the few rows is the caller's A
+        if (op == OP_AND and not rowwise and algo is None and self.id_bits == 32 and other.id_bits == 32 and pairs
+                and self.n_rows <= 32 and 0 < other.width <= 4096 and other.max_row_len <= 64
+                and self.data_kind != DATA_ARITH and other.data_kind != DATA_ARITH and few is not None):
+            # One query, or a handful, against a database: offsets and elements in one enqueue, the element buffers
+            # sized by the expected number of matches (ids spread evenly over the width) with room to spare.
+            expected = self.nnz * other.nnz / other.width
+            cap = int(min(min(self.nnz * other.n_rows, other.nnz * self.n_rows), expected * 1.3 + 8.0 * expected ** 0.5 + 4096))
+            has_data = this_kind != DATA_EMPTY
+
+            def run(capacity):
+                off_t = torch.empty(pairs + 1, dtype=torch.int32, device=dev)
+                ids_t = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+                data_t = torch.empty(max(capacity, 1), dtype=torch.float32, device=dev) if has_data else None
+                tot_t = torch.empty(1, dtype=torch.int64, device=dev)
+                check(self._lib.sdrb_ande_few(self._h, other._h, flags & FLAG_SWAP, off_t.data_ptr(), ids_t.data_ptr(),
+                                              data_t.data_ptr() if data_t is not None else None, capacity,
+                                              tot_t.data_ptr(), s))
+                return off_t, ids_t, data_t, tot_t
+
+            try:
+                off_t, ids_t, data_t, tot_t = run(cap)
+                return ElemResult(self.n_rows, other.n_rows, off_t, ids_t, data_t, total_dev=tot_t,
+                                  refill=lambda total: run(total)[:3])
+            except _lib.SdrbError as e:
+                if e.code != -5:        # not served (tables too large for LDS): the count / fill protocol below
+                    raise
         if op != OP_AND and self.id_bits == 32 and other.id_bits == 32 and pairs:
             # Unions and differences: the shapes bound the result tightly (|A_i| + |B_j| per pair), so the buffers
             # are sized by the bound and count, scan and fill are enqueued in one call, with no wait in between.

@@ -1341,6 +1341,36 @@ int sdrb_elem_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return sdrb_elem_op_fill(a, b, op, flags, out_offsets, out_ids, out_data, stream);
 }
 
+int sdrb_ande_few(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out_offsets, int32_t* out_ids,
+                  float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream) {
+    int rc = check_pair(a, b, SDRB_OP_AND);
+    if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_ande_few");
+    if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
+    if (rc != SDRB_OK) return rc;
+    if (flags & ~SDRB_FLAG_SWAP) {
+        set_error("sdrb_ande_few takes SDRB_FLAG_SWAP only");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    if (!few_ande_applicable(a, b, swap)) {
+        set_error("sdrb_ande_few serves 1..32 rows of a, a declared width <= 4096 on b, rows of b <= 64 ids, EmptyData or "
+                  "UnitData payloads");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    const sdrb_batch* self = swap ? b : a;
+    if (!out_offsets || !total_dev || (capacity && (!out_ids || (has_payload(self) && !out_data)))) {
+        set_error("sdrb_ande_few: null output (results with payloads need out_data)");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_few_ande(a, b, swap, out_offsets, out_ids, out_data, capacity,
+                           reinterpret_cast<unsigned long long*>(total_dev), static_cast<hipStream_t>(stream));
+}
+
 namespace {
 int check_visit(const sdrb_batch* a, const sdrb_batch* b, int which) {
     if (!a || !b) {

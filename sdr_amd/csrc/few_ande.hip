@@ -1,0 +1,368 @@
+// ande of a few rows of A (at most 32: one query, or a handful) with every row of a database B, in one call with no
+// pass over per-pair offsets in between:  result(i, j) = the kept common ids of A_i and B_j, ascending, with the
+// combined payload (SDR.hpp:999-1025; UnitData.hpp:30-51 for the payload rule).
+//
+// At SDR densities such a result is sparse -- 0.78 elements a pair at 2048/40 -- so the CSR offsets (4 bytes a pair)
+// outweigh the elements, and a count -> scan -> fill pipeline over 16.7 M pairs spends more time on the offsets
+// (write, scan, read again) than on finding the matches.  Here a lane owns one row of B (ids and payloads in
+// registers) and walks it against the 32-row tile tables of A in LDS (lane_tiles.h), as in lane_rows.hip, and
+//
+//   (1) k_few_ande_count : walk; per pair the number of kept matches as ONE BYTE (a row of B holds at most 64 ids),
+//                          per (row of A, 256-row group of B) their sum;
+//   (2) k_few_ande_scan  : one workgroup scans the group sums (na x groups values) in pair order and leaves the
+//                          element total in device memory;
+//   (3) k_few_ande_fill  : reads its pairs' bytes, scans them over the lanes of the group (DPP wave scans), writes
+//                          the offsets, walks the row again and writes every kept match at its pair's cursor -- a
+//                          lane walks its row in ascending id order, so a pair's elements come out in id order.
+//
+// The caller sizes the element buffers by an estimate or a bound; elements beyond `capacity` are not written (the
+// total tells the caller, who calls again with room).  Offsets are always complete.
+#include <type_traits>
+
+#include "lane_tiles.h"
+#include "match_math.h"
+#include "sdrb_internal.h"
+
+namespace sdrb {
+
+namespace {
+
+constexpr int kWaves = kBlock / 64;
+
+template <int MATH>
+constexpr bool need_a() { return MATH == kSelfA || MATH == kMul; }
+template <int MATH>
+constexpr bool need_b() { return MATH == kSelfB || MATH == kMul; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// The lane's row of B: ids as byte offsets of their mask words (rows shorter than 8*NCH are padded with the
+// sentinel id, whose mask is zero), payloads, and the row's length.
+template <int NCH, bool BV>
+__device__ __forceinline__ void load_row(const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
+                                         const float* __restrict__ b_val, uint32_t nb, uint32_t j0, uint32_t tid,
+                                         uint32_t wcap, uint32_t (&id)[8 * NCH], float (&val)[8 * NCH], uint32_t& lb) {
+    const uint32_t j = j0 + tid;
+    uint32_t beg = 0;
+    lb = 0;
+    if (j < nb) {
+        beg = b_off[j];
+        lb = b_off[j + 1] - beg;
+    }
+    // bounds-checked buffers that start at the group's first element: loads are unconditional
+    const uint32_t blk_beg = b_off[j0];
+    const uint32_t blk_last = j0 + kBlock < nb ? j0 + kBlock : nb;
+    const uint32_t blk_bytes = (b_off[blk_last] - blk_beg) * 4u;
+    __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(b_ids) + blk_beg, 0,
+                                                                        (int)blk_bytes, 0x00020000);
+    const uint32_t rel = (beg - blk_beg) * 4u;
+#pragma unroll
+    for (int k4 = 0; k4 < 2 * NCH; ++k4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ids_rsrc, (int)(rel + 16u * k4), 0, 0);
+        id[4 * k4 + 0] = v[0];
+        id[4 * k4 + 1] = v[1];
+        id[4 * k4 + 2] = v[2];
+        id[4 * k4 + 3] = v[3];
+    }
+    if constexpr (BV) {
+        __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_val) + blk_beg, 0,
+                                                                            (int)blk_bytes, 0x00020000);
+#pragma unroll
+        for (int k4 = 0; k4 < 2 * NCH; ++k4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(val_rsrc, (int)(rel + 16u * k4), 0, 0);
+            val[4 * k4 + 0] = __uint_as_float(v[0]);
+            val[4 * k4 + 1] = __uint_as_float(v[1]);
+            val[4 * k4 + 2] = __uint_as_float(v[2]);
+            val[4 * k4 + 3] = __uint_as_float(v[3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8 * NCH; ++k) {
+        const bool live = (uint32_t)k < lb;
+        id[k] = (live ? id[k] : wcap) * 4u;
+        val[k] = (BV && live) ? val[k] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const unsigned char* __restrict__ tables, uint32_t tile_bytes,
+                                           uint32_t tid) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(tables);
+    for (uint32_t v = tid; v < tile_bytes / 16u; v += kBlock) reinterpret_cast<u32x4*>(lds)[v] = src[v];
+}
+
+// Walks the lane's row: `hit(q, id, d)` for every kept match with row q of A, in ascending id order.
+template <int MATH, int NCH, typename Hit>
+__device__ __forceinline__ void walk(const unsigned char* tab, uint32_t col_at, const uint32_t (&id)[8 * NCH],
+                                     const float (&val)[8 * NCH], Hit&& hit) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        uint32_t m[8], c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t o = id[ch * 8 + k];
+            m[k] = *reinterpret_cast<const uint32_t*>(tab + o);
+            c[k] = need_a<MATH>() ? *reinterpret_cast<const uint16_t*>(tab + col_at + (o >> 1)) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t mm = m[k], cc = c[k];
+            while (mm != 0) {
+                const uint32_t q = (uint32_t)__builtin_ctz(mm);
+                mm &= mm - 1;
+                float va = 0.0f;
+                if constexpr (need_a<MATH>()) {
+                    va = *reinterpret_cast<const float*>(tab + cc);
+                    cc += 4;
+                }
+                float d;
+                if (match_kept_by<MATH>(va, val[ch * 8 + k], d)) hit(q, id[ch * 8 + k] >> 2, d);
+            }
+        }
+    }
+}
+
+// (1) bytes per pair and sums per (row of A, group of B)
+template <int MATH, int NCH>
+__global__ __launch_bounds__(kBlock) void k_few_ande_count(
+    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, const float* __restrict__ b_val, uint32_t nb,
+    const unsigned char* __restrict__ tables, uint32_t tile_bytes, uint32_t wcap, uint32_t na,
+    uint8_t* __restrict__ cnt8, uint32_t* __restrict__ group_total, uint32_t n_groups) {
+    // LDS: the tile's tables | acc[na][256] | wave_part[na][4]
+    extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* acc_lane = reinterpret_cast<uint32_t*>(few_lds + tile_bytes) + tid;
+    uint32_t* wave_part = reinterpret_cast<uint32_t*>(few_lds + tile_bytes) + na * kBlock;
+    stage_tile(few_lds, tables, tile_bytes, tid);
+    for (uint32_t q = 0; q < na; ++q) acc_lane[q * kBlock] = 0u;
+    __syncthreads();
+    const uint32_t col_at = mask_bytes(wcap);
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t j0 = g * kBlock, j = j0 + tid;
+        uint32_t id[8 * NCH], lb;
+        float val[8 * NCH];
+        load_row<NCH, need_b<MATH>()>(b_off, b_ids, b_val, nb, j0, tid, wcap, id, val, lb);
+        walk<MATH, NCH>(few_lds, col_at, id, val, [&](uint32_t q, uint32_t, float) {
+            uint32_t* slot = acc_lane + q * kBlock;
+            *slot = *slot + 1u;
+        });
+        for (uint32_t q = 0; q < na; ++q) {
+            const uint32_t c = acc_lane[q * kBlock];
+            acc_lane[q * kBlock] = 0u;
+            if (j < nb) cnt8[(uint64_t)q * nb + j] = (uint8_t)c;
+            const uint32_t incl = wave_inclusive_scan(c);
+            if (lane == 63) wave_part[q * kWaves + wave] = incl;
+        }
+        __syncthreads();
+        if (tid < na) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) s += wave_part[tid * kWaves + w];
+            group_total[(uint64_t)tid * n_groups + g] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// (2) group sums -> where every (row of A, group of B) starts in the result, in pair order (row of A major); the
+//     element total; the last offset.  One workgroup per row of A: it adds up the rows before its own (a few thousand
+//     values each) and scans its own.
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_few_ande_scan(uint32_t* __restrict__ group_total, uint32_t na,
+                                                               uint32_t n_groups,
+                                                               unsigned long long* __restrict__ total_out,
+                                                               uint32_t* __restrict__ last_offset) {
+    __shared__ unsigned long long part64[kScanThreads / 64];
+    __shared__ uint32_t part32[kScanThreads / 64];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // elements of the rows of A before this one
+    unsigned long long before = 0;
+    const uint64_t n_before = (uint64_t)q * n_groups;
+    for (uint64_t k = tid; k < n_before; k += kScanThreads) before += group_total[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += (unsigned long long)__shfl_xor((long long)before, d, 64);
+    if (lane == 0) part64[wave] = before;
+    __syncthreads();
+    before = 0;
+    for (int w = 0; w < kScanThreads / 64; ++w) before += part64[w];
+    // this row: every thread owns a run of consecutive groups
+    uint32_t* row = group_total + (uint64_t)q * n_groups;
+    const uint32_t per = (n_groups + kScanThreads - 1) / kScanThreads;
+    const uint32_t g0 = tid * per < n_groups ? tid * per : n_groups, g1 = g0 + per < n_groups ? g0 + per : n_groups;
+    uint32_t mine = 0;
+    for (uint32_t g = g0; g < g1; ++g) mine += row[g];
+    const uint32_t incl = wave_inclusive_scan(mine);
+    if (lane == 63) part32[wave] = incl;
+    __syncthreads();
+    uint32_t run = (uint32_t)before + incl - mine;   // offsets are kept modulo 2^32; the 64-bit total says whether they are valid
+    uint32_t row_sum = 0;
+    for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+        if (w < wave) run += part32[w];
+        row_sum += part32[w];
+    }
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint32_t v = row[g];
+        row[g] = run;
+        run += v;
+    }
+    if (q + 1 == na && tid == 0) {
+        *total_out = before + row_sum;
+        *last_offset = (uint32_t)(before + row_sum);
+    }
+}
+
+// (3) offsets and elements.  (Collecting a group's matches in LDS and writing them out as coalesced runs was tried:
+//     the 16 KB stage costs a resident block per compute unit and two more barriers a group, 151 against 118 us.)
+template <int MATH, int NCH>
+__global__ __launch_bounds__(kBlock) void k_few_ande_fill(
+    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, const float* __restrict__ b_val, uint32_t nb,
+    const unsigned char* __restrict__ tables, uint32_t tile_bytes, uint32_t wcap, uint32_t na,
+    const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ group_base, uint32_t n_groups,
+    uint32_t* __restrict__ out_offsets, int32_t* __restrict__ out_ids, float* __restrict__ out_data, uint64_t capacity) {
+    // LDS: the tile's tables | acc[na][256] | wave_part[na][4]
+    extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* acc_lane = reinterpret_cast<uint32_t*>(few_lds + tile_bytes) + tid;
+    uint32_t* wave_part = reinterpret_cast<uint32_t*>(few_lds + tile_bytes) + na * kBlock;
+    stage_tile(few_lds, tables, tile_bytes, tid);
+    __syncthreads();
+    const uint32_t col_at = mask_bytes(wcap);
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t j0 = g * kBlock, j = j0 + tid;
+        uint32_t id[8 * NCH], lb;
+        float val[8 * NCH];
+        load_row<NCH, need_b<MATH>()>(b_off, b_ids, b_val, nb, j0, tid, wcap, id, val, lb);
+        // this lane's pairs: exclusive prefix of their sizes over the wave, the waves' sums for the block
+        for (uint32_t q = 0; q < na; ++q) {
+            const uint32_t c = j < nb ? (uint32_t)cnt8[(uint64_t)q * nb + j] : 0u;
+            const uint32_t incl = wave_inclusive_scan(c);
+            acc_lane[q * kBlock] = incl - c;
+            if (lane == 63) wave_part[q * kWaves + wave] = incl;
+        }
+        __syncthreads();
+        for (uint32_t q = 0; q < na; ++q) {
+            uint32_t base = group_base[(uint64_t)q * n_groups + g];
+            for (uint32_t w = 0; w < wave; ++w) base += wave_part[q * kWaves + w];
+            const uint32_t pos = base + acc_lane[q * kBlock];
+            acc_lane[q * kBlock] = pos;
+            if (j < nb) out_offsets[(uint64_t)q * nb + j] = pos;
+        }
+        walk<MATH, NCH>(few_lds, col_at, id, val, [&](uint32_t q, uint32_t w, float d) {
+            uint32_t* slot = acc_lane + q * kBlock;
+            const uint32_t p = *slot;
+            *slot = p + 1u;
+            if ((uint64_t)p < capacity) {
+                out_ids[p] = (int32_t)w;
+                if constexpr (MATH != kKeepAll) out_data[p] = d;
+            }
+        });
+        __syncthreads();   // wave_part is rewritten by the next group
+    }
+}
+
+struct FewPlan {
+    int wcap, nch, math;
+    uint32_t tile_bytes, ntiles, n_groups, grid;
+    size_t lds;
+};
+
+bool make_plan(const sdrb_batch* a, const sdrb_batch* b, bool swap, FewPlan* p) {
+    if (a->id_bits != 32 || b->id_bits != 32 || a->n_rows == 0 || a->n_rows > (uint64_t)kTile || b->n_rows == 0) return false;
+    if (b->n_rows > 0xFFFFFF00ull) return false;
+    if (b->width <= 0 || b->width > 4096 || b->max_row_len > 64 || a->max_row_len > 1024) return false;
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) return false;
+    p->math = pick_math(a, b, SDRB_OP_AND, swap);
+    p->wcap = b->width <= 2048 ? 2048 : 4096;
+    p->nch = b->max_row_len <= 40 ? 5 : 8;
+    const bool with_vals = p->math == kSelfA || p->math == kMul;
+    const uint32_t val_cap = with_vals ? ((uint32_t)kTile * (a->max_row_len ? a->max_row_len : 1u) + 3u) & ~3u : 0u;
+    p->tile_bytes = mask_bytes((uint32_t)p->wcap) + col_bytes((uint32_t)p->wcap) + val_cap * 4u + kLenBytes;
+    p->lds = (size_t)p->tile_bytes + (size_t)a->n_rows * kBlock * 4u + (size_t)kTile * kWaves * 4u;
+    if (p->lds > 160 * 1024 - 512) return false;
+    p->n_groups = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
+    // blocks stay resident and stride over the groups, so the tables are staged once per block
+    const uint32_t per_cu = (uint32_t)((160u * 1024u) / (p->lds + 512));
+    const uint32_t resident = 256u * (per_cu < 8u ? per_cu : 8u);
+    p->grid = p->n_groups < resident ? p->n_groups : resident;
+    return true;
+}
+
+template <int MATH, int NCH>
+int launch_all(const sdrb_batch* a, const sdrb_batch* b, const FewPlan& p, const unsigned char* tables, uint8_t* cnt8,
+               uint32_t* group_total, uint32_t* out_offsets, int32_t* out_ids, float* out_data, uint64_t capacity,
+               unsigned long long* total_dev, hipStream_t stream) {
+    const uint32_t na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
+    if (p.lds > 64 * 1024) {   // dynamic LDS beyond 64 KiB has to be granted per kernel
+        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_few_ande_count<MATH, NCH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+        SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_few_ande_fill<MATH, NCH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    }
+    hipLaunchKernelGGL((k_few_ande_count<MATH, NCH>), dim3(p.grid), dim3(kBlock), p.lds, stream, b->d_offsets, b->d_ids,
+                       b->d_data, nb, tables, p.tile_bytes, (uint32_t)p.wcap, na, cnt8, group_total, p.n_groups);
+    SDRB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, na, p.n_groups, total_dev,
+                       out_offsets + (uint64_t)na * nb);
+    SDRB_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_few_ande_fill<MATH, NCH>), dim3(p.grid), dim3(kBlock), p.lds, stream, b->d_offsets, b->d_ids,
+                       b->d_data, nb, tables, p.tile_bytes, (uint32_t)p.wcap, na, cnt8, group_total, p.n_groups, out_offsets,
+                       out_ids, out_data, capacity);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+template <int MATH>
+int launch_nch(const sdrb_batch* a, const sdrb_batch* b, const FewPlan& p, const unsigned char* tables, uint8_t* cnt8,
+               uint32_t* group_total, uint32_t* out_offsets, int32_t* out_ids, float* out_data, uint64_t capacity,
+               unsigned long long* total_dev, hipStream_t stream) {
+    if (p.nch == 5)
+        return launch_all<MATH, 5>(a, b, p, tables, cnt8, group_total, out_offsets, out_ids, out_data, capacity, total_dev, stream);
+    return launch_all<MATH, 8>(a, b, p, tables, cnt8, group_total, out_offsets, out_ids, out_data, capacity, total_dev, stream);
+}
+
+}  // namespace
+
+bool few_ande_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap) {
+    FewPlan p;
+    return make_plan(a, b, swap, &p);
+}
+
+// out_offsets[na*nb + 1], out_ids / out_data[capacity] (out_data only when `this` carries payloads), *total_dev: the
+// element total (device memory).  Elements at positions >= capacity are not written.
+int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_t* out_offsets, int32_t* out_ids,
+                    float* out_data, uint64_t capacity, unsigned long long* total_dev, hipStream_t stream) {
+    FewPlan p;
+    if (!make_plan(a, b, swap, &p)) {
+        set_error("the fused few-rows ande serves at most 32 rows of a, a declared width <= 4096 and rows of b <= 64 ids");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    const bool with_vals = p.math == kSelfA || p.math == kMul;
+    const unsigned char* tables = nullptr;
+    uint32_t tile_bytes = 0, ntiles = 0;
+    int rc = build_lane_tiles(a, b->device, p.wcap, with_vals, stream, &tile_bytes, &ntiles, &tables);
+    if (rc != SDRB_OK) return rc;
+    const size_t cnt_bytes = ((size_t)a->n_rows * b->n_rows + 255) & ~(size_t)255;
+    char* ws = static_cast<char*>(workspace(b->device, stream, 12, cnt_bytes + (size_t)a->n_rows * p.n_groups * sizeof(uint32_t)));
+    if (!ws) return SDRB_ERR_HIP;
+    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(ws);
+    uint32_t* group_total = reinterpret_cast<uint32_t*>(ws + cnt_bytes);
+    switch (p.math) {
+    case kKeepAll:
+        return launch_nch<kKeepAll>(a, b, p, tables, cnt8, group_total, out_offsets, out_ids, out_data, capacity, total_dev, stream);
+    case kSelfA:
+        return launch_nch<kSelfA>(a, b, p, tables, cnt8, group_total, out_offsets, out_ids, out_data, capacity, total_dev, stream);
+    case kSelfB:
+        return launch_nch<kSelfB>(a, b, p, tables, cnt8, group_total, out_offsets, out_ids, out_data, capacity, total_dev, stream);
+    default:
+        return launch_nch<kMul>(a, b, p, tables, cnt8, group_total, out_offsets, out_ids, out_data, capacity, total_dev, stream);
+    }
+}
+
+}  // namespace sdrb

@@ -197,6 +197,12 @@ int launch_merge_topk(const int* partial, uint32_t na, uint32_t splits, uint32_t
                       uint64_t rows_per_split, uint32_t k, uint32_t* out_counts, int32_t* out_rows,
                       hipStream_t stream);
 
+// few_ande.hip: ande of at most 32 rows of a with every row of b, offsets and elements in one enqueue (bytes per pair,
+// a scan of per-group sums, then the fill); elements beyond `capacity` are not written
+bool few_ande_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);
+int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_t* out_offsets, int32_t* out_ids,
+                    float* out_data, uint64_t capacity, unsigned long long* total_dev, hipStream_t stream);
+
 // mask_table.hip ---------------------------------------------------------------------------
 // Size ops with a 64-row query-mask table in LDS: B is read once per 64 rows of A (width <= ~17800).
 bool mask_table_applicable(const sdrb_batch* a, const sdrb_batch* b);

@@ -665,3 +665,41 @@ def test_64_bit_batches_whose_ids_fit_32_bits_take_the_fast_kernels(name):
         off, ids, data = gpu_elems(op, n_t, n_a)
         w_off, w_ids, w_data = oracle.port().elem_op(op, neg_t, neg_a)
         assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids.astype(np.int64)), op
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("nq,width,len_t,len_a,na", [(1, 2048, 40, 40, 3000), (16, 2048, 40, 40, 1300), (32, 4096, 200, 64, 700),
+                                                     (7, 64, 64, 64, 513), (3, 2048, 0, 40, 300), (5, 2000, 40, 0, 300),
+                                                     (2, 2048, 1024, 33, 257)])
+def test_fused_few_rows_ande_vs_oracle(name, nq, width, len_t, len_a, na):
+    """ande of 1..32 rows against a database through the fused path (bytes per pair, a scan of per-group sums, offsets
+    and elements in one enqueue): elements in id order, payload bits, both orientations, partial groups, and a second
+    pass when the estimate-sized buffers turn out too small."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(11 + 2 * tu + au + width + nq)
+    empty = lambda n, unit: Batch(np.zeros(n + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if unit else None)   # noqa: E731
+    t = Batch(*util.ragged_rows(rng, nq, width, len_t, tu)) if len_t else empty(nq, tu)
+    a = Batch(*util.ragged_rows(rng, na, width, len_a, au)) if len_a else empty(na, au)
+    dt, da = dev(t, width), dev(a, width)
+    res = dt.ande(da)
+    assert res._total_dev is not None          # the fused path: total still on the device
+    assert_elems_equal(res.to_host(), oracle.port().elem_op(AND, t, a))
+    assert_elems_equal(gpu_elems(AND, dt, da, algo="merge"), oracle.port().elem_op(AND, t, a))
+    off, ids, data = gpu_elems(AND, dt, da, swap=True)
+    w_off, w_ids, w_data = oracle.port().elem_op(AND, a, t)
+    assert np.array_equal(np.diff(off).reshape(t.n, a.n), np.diff(w_off).reshape(a.n, t.n).T)
+    assert np.array_equal(util.pair_digests(off, ids, data).reshape(t.n, a.n),
+                          util.pair_digests(w_off, w_ids, w_data).reshape(a.n, t.n).T)
+
+
+@pytest.mark.gpu
+def test_fused_few_rows_ande_refills_when_the_estimate_is_too_small():
+    # every row of both batches holds the same 40 ids: 40 matches a pair where a uniform spread predicts 0.78
+    ids = np.tile(np.arange(100, 140, dtype=np.int32), 600)
+    off = np.arange(601, dtype=np.uint64) * 40
+    t = Batch(off[:5], ids[: 4 * 40], None)
+    a = Batch(off, ids, None)
+    res = dev(t, 2048).ande(dev(a, 2048))
+    assert res.total == 4 * 600 * 40 and res.ids.numel() == res.total
+    assert_elems_equal(res.to_host(), oracle.port().elem_op(AND, t, a))
