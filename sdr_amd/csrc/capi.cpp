@@ -11,6 +11,8 @@
 #include <tuple>
 #include <vector>
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "sdrb_internal.h"
 
 namespace sdrb {
@@ -18,6 +20,15 @@ namespace sdrb {
 namespace {
 
 thread_local std::string g_error;
+
+// A named range around the host side of an entry point, for `rocprofv3 --marker-trace`: the kernels an entry
+// point enqueues show up under its name.  Without a profiler attached the two calls do nothing.
+struct TraceRange {
+    explicit TraceRange(const char* name) { (void)roctxRangePushA(name); }
+    ~TraceRange() { (void)roctxRangePop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
 
 struct DeviceGuard {
     int prev = -1;
@@ -475,6 +486,7 @@ static int sdrb_batch_upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, cons
 }
 
 int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets, const int64_t* ids, const float* data, void* stream) {
+    TraceRange range("sdrb_batch_upload_csr64");
     return sdrb::guarded("sdrb_batch_upload_csr64", [&] { return sdrb_batch_upload_csr64_impl(batch, n_rows, row_offsets, ids, data, stream); });
 }
 
@@ -586,11 +598,13 @@ static int sdrb_batch_upload_csr_impl(sdrb_batch* batch, uint64_t n_rows, const 
 }
 
 int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids, const float* data, void* stream) {
+    TraceRange range("sdrb_batch_upload_csr");
     return sdrb::guarded("sdrb_batch_upload_csr", [&] { return sdrb_batch_upload_csr_impl(batch, n_rows, row_offsets, ids, data, stream); });
 }
 
 int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint32_t* row_offsets,
                                  const int32_t* ids, const float* data, void* stream) {
+    TraceRange range("sdrb_batch_upload_device_csr");
     if (!batch || !row_offsets) {
         set_error("sdrb_batch_upload_device_csr: null argument");
         return SDRB_ERR_INVALID_ARG;
@@ -666,6 +680,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
 int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz, const uint32_t* row_offsets,
                                 const int32_t* ids, const float* data, uint32_t max_row_len,
                                 int32_t min_id, int32_t max_id) {
+    TraceRange range("sdrb_batch_adopt_device_csr");
     if (!batch || !row_offsets || (nnz && !ids) ||
         (nnz && has_payload(batch) && !data)) {
         set_error("sdrb_batch_adopt_device_csr: null argument");
@@ -721,6 +736,7 @@ int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id
 
 int sdrb_batch_export_device_csr(const sdrb_batch* batch, uint32_t* row_offsets, int32_t* ids, float* data,
                                  void* stream) {
+    TraceRange range("sdrb_batch_export_device_csr");
     if (!batch || !batch->d_offsets || !row_offsets || (batch->nnz && !ids) ||
         (batch->nnz && has_payload(batch) && !data)) {
         set_error("sdrb_batch_export_device_csr: null argument or empty handle");
@@ -763,6 +779,7 @@ int sdrb_batch_destroy(sdrb_batch* batch) {
 
 int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                  uint64_t ld_out, void* stream) {
+    TraceRange range("sdrb_size_op");
     narrow_pair(a, b, flags);
     int rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
@@ -847,6 +864,7 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
 
 int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                         uint64_t ld_out, void* stream) {
+    TraceRange range("sdrb_size_op_static");
     int rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_size_op_static");
     if (rc != SDRB_OK) return rc;
@@ -876,6 +894,7 @@ int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
 }
 
 int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream) {
+    TraceRange range("sdrb_equal");
     narrow_pair(a, b, flags);
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
@@ -940,6 +959,7 @@ static int sdrb_batch_transpose_impl(const sdrb_batch* src, sdrb_batch* dst, voi
 }
 
 int sdrb_batch_transpose(const sdrb_batch* src, sdrb_batch* dst, void* stream) {
+    TraceRange range("sdrb_batch_transpose");
     return sdrb::guarded("sdrb_batch_transpose", [&] { return sdrb_batch_transpose_impl(src, dst, stream); });
 }
 
@@ -997,6 +1017,7 @@ int check_queries(const sdrb_batch* b, uint64_t n, const int32_t* lo, const int3
 
 int sdrb_range_size(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
                     uint32_t* out, uint64_t ld_out, void* stream) {
+    TraceRange range("sdrb_range_size");
     int rc = check_queries(b, n_ranges, lo, hi, true);
     if (rc != SDRB_OK) return rc;
     if (n_ranges == 0 || b->n_rows == 0) return SDRB_OK;
@@ -1011,6 +1032,7 @@ int sdrb_range_size(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, c
 
 int sdrb_range_elems_count(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
                            uint32_t* out_offsets, uint64_t* total, void* stream) {
+    TraceRange range("sdrb_range_elems_count");
     int rc = check_queries(b, n_ranges, lo, hi, true);
     if (rc != SDRB_OK) return rc;
     if (!out_offsets || !total) {
@@ -1033,6 +1055,7 @@ int sdrb_range_elems_count(const sdrb_batch* b, uint64_t n_ranges, const int32_t
 
 int sdrb_range_elems_fill(const sdrb_batch* b, uint64_t n_ranges, const int32_t* lo, const int32_t* hi,
                           const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
+    TraceRange range("sdrb_range_elems_fill");
     int rc = check_queries(b, n_ranges, lo, hi, true);
     if (rc != SDRB_OK) return rc;
     if (n_ranges == 0 || b->n_rows == 0) return SDRB_OK;
@@ -1047,6 +1070,7 @@ int sdrb_range_elems_fill(const sdrb_batch* b, uint64_t n_ranges, const int32_t*
 
 int sdrb_point_query(const sdrb_batch* b, uint64_t n_ids, const int32_t* ids, int32_t* out, uint64_t ld_out,
                      void* stream) {
+    TraceRange range("sdrb_point_query");
     int rc = check_queries(b, n_ids, ids, nullptr, false);
     if (rc != SDRB_OK) return rc;
     if (n_ids == 0 || b->n_rows == 0) return SDRB_OK;
@@ -1061,6 +1085,7 @@ int sdrb_point_query(const sdrb_batch* b, uint64_t n_ids, const int32_t* ids, in
 
 int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
                void* stream) {
+    TraceRange range("sdrb_inner");
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_inner");
     if (rc != SDRB_OK) return rc;
@@ -1084,6 +1109,7 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
 
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
+    TraceRange range("sdrb_allpairs_topk");
     narrow_pair(a, b, 0);
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_allpairs_topk");
@@ -1157,6 +1183,7 @@ uint64_t elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                        uint32_t* out_offsets, uint64_t* total, void* stream) {
+    TraceRange range("sdrb_elem_op_count");
     narrow_pair(a, b, flags);
     uint64_t pairs = 0;
     int rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
@@ -1299,16 +1326,19 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
 
 int sdrb_elem_op_fill(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                       const uint32_t* out_offsets, int32_t* out_ids, float* out_data, void* stream) {
+    TraceRange range("sdrb_elem_op_fill");
     return elem_op_fill_any(a, b, op, flags, out_offsets, out_ids, 32, out_data, stream);
 }
 
 int sdrb_elem_op_fill64(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                         const uint32_t* out_offsets, int64_t* out_ids, float* out_data, void* stream) {
+    TraceRange range("sdrb_elem_op_fill64");
     return elem_op_fill_any(a, b, op, flags, out_offsets, out_ids, 64, out_data, stream);
 }
 
 int sdrb_elem_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out_offsets,
                  int32_t* out_ids, float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream) {
+    TraceRange range("sdrb_elem_op");
     uint64_t pairs = 0;
     int rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_elem_op");
@@ -1343,6 +1373,7 @@ int sdrb_elem_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
 
 int sdrb_ande_few(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out_offsets, int32_t* out_ids,
                   float* out_data, uint64_t capacity, uint64_t* total_dev, void* stream) {
+    TraceRange range("sdrb_ande_few");
     int rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_ande_few");
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
@@ -1387,6 +1418,7 @@ int check_visit(const sdrb_batch* a, const sdrb_batch* b, int which) {
 
 int sdrb_visit_count(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, uint32_t* out_offsets,
                      uint64_t* total, void* stream) {
+    TraceRange range("sdrb_visit_count");
     const int rc = check_visit(a, b, which);
     if (rc != SDRB_OK) return rc;
     IdView va(a), vb(b);
@@ -1397,6 +1429,7 @@ int sdrb_visit_count(const sdrb_batch* a, const sdrb_batch* b, int which, unsign
 
 int sdrb_visit_fill(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, const uint32_t* out_offsets,
                     uint32_t* this_pos, uint32_t* arg_pos, void* stream) {
+    TraceRange range("sdrb_visit_fill");
     int rc = check_visit(a, b, which);
     const int op = which == SDRB_VISIT_AND ? SDRB_OP_AND : SDRB_OP_OR;
     if (rc == SDRB_OK) rc = check_pair(a, b, op);

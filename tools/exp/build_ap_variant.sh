@@ -9,5 +9,5 @@ name=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" \
    -I. -c -o /tmp/ap_var.o ../../tools/exp/allpairs_mfma_lab.hip
 objs=$(ls _obj/*.o | grep -v allpairs_mfma)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libsdr_amd_ap_$name.so $objs /tmp/ap_var.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libsdr_amd_ap_$name.so $objs /tmp/ap_var.o -L/opt/rocm/lib -lrocprofiler-sdk-roctx
 echo built tools/exp/libsdr_amd_ap_$name.so

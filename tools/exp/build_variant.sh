@@ -10,5 +10,5 @@ base=$(basename "$src" .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" \
    -c -o /tmp/var_$name.o "$src"
 objs=$(ls _obj/*.o | grep -v "_obj/$base.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libsdr_amd_$name.so $objs /tmp/var_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libsdr_amd_$name.so $objs /tmp/var_$name.o -L/opt/rocm/lib -lrocprofiler-sdk-roctx
 echo built tools/exp/libsdr_amd_$name.so

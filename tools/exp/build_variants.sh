@@ -9,6 +9,6 @@ for cfg in "$@"; do
   out=../../tools/exp/libsdr_amd_$1_$2.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
      -DSDRB_BS_BLOCK=$1 -DSDRB_BS_MIN_WAVES=$2 $3 -c -o /tmp/bs_var.o size_bitslice.hip
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $(ls _obj/*.o | grep -v size_bitslice) /tmp/bs_var.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $(ls _obj/*.o | grep -v size_bitslice) /tmp/bs_var.o -L/opt/rocm/lib -lrocprofiler-sdk-roctx
   echo built $out
 done
