@@ -537,6 +537,29 @@ def test_lane_rows_size_kernel_vs_oracle(name, width, len_t, len_a, nt, na):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("width", [40, 64])
+def test_lane_rows_size_kernel_with_every_id_matching(width):
+    """Rows that hold every id of the width: every pair matches in `width` ids, the largest count the kernel's
+    bit-sliced counters take (64 matches, and 64 + 64 for xors when every match is dropped), and every id of a
+    tile is held by all 32 rows (the bit loop's longest run)."""
+    rng = np.random.default_rng(width)
+    nt, na = 70, 300
+
+    def full(n, low, high):
+        off = np.arange(n + 1, dtype=np.uint64) * width
+        ids = np.tile(np.arange(width, dtype=np.int32), n)
+        return Batch(off, ids, rng.uniform(low, high, n * width).astype(np.float32))
+
+    for low, high in ((0.0, 1.0), (0.5, 0.5), (0.0, 0.05)):     # mixed, all kept by ands / all dropped by xors, none kept
+        t, a = full(nt, low, high), full(na, low, high)
+        dt, da = dev(t, width), dev(a, width)
+        for op in (AND, XOR, RM):
+            for swap in (False, True):
+                want = oracle.port().size_op(op, a, t).T if swap else oracle.port().size_op(op, t, a)
+                assert np.array_equal(gpu_sizes(op, dt, da, swap=swap, algo="lanerows"), want), (low, op, swap)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", list(PAIRINGS))
 @pytest.mark.parametrize("nq,width,len_a,len_b", [(1, 2048, 40, 40), (8, 2048, 40, 40), (3, 4099, 300, 64), (5, 33, 33, 20),
                                                   (8, 17000, 90, 7), (2, 1, 1, 1), (9, 2048, 40, 40), (16, 2049, 64, 64),
