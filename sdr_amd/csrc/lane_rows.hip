@@ -543,6 +543,10 @@ int launch_size_lane_rows(const sdrb_batch* a, const sdrb_batch* b, int op, bool
     g.out = out;
     g.ld_out = ld_out;
     const int wcap = b->width <= 2048 ? 2048 : 4096;
+    if (g.tile_bytes > lane_tile_cap((uint32_t)wcap)) {   // the kernel's LDS array holds the largest tile shapes_fit admits
+        set_error("lane-per-row size kernel: a tile of %u bytes exceeds the kernel's table", g.tile_bytes);
+        return SDRB_ERR_UNSUPPORTED;
+    }
     switch (math) {
     case kSelfA: launch_size_m<kSelfA>(g, wcap); break;
     case kSelfB: launch_size_m<kSelfB>(g, wcap); break;
