@@ -22,6 +22,7 @@
 // Link with -lsdr_amd (no HIP headers needed here).  Errors become sdr_amd::Error.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -302,7 +303,8 @@ class SDRBatch {
     SDRBatch(const SDRBatch&) = delete;
     SDRBatch& operator=(const SDRBatch&) = delete;
     SDRBatch(SDRBatch&& o) noexcept
-        : h_(o.h_), device_(o.device_), n_rows_(o.n_rows_), kind_(o.kind_), id_bits_(o.id_bits_) { o.h_ = nullptr; }
+        : h_(o.h_), device_(o.device_), n_rows_(o.n_rows_), kind_(o.kind_), id_bits_(o.id_bits_),
+          view_data_(std::move(o.view_data_)) { o.h_ = nullptr; }
     ~SDRBatch() { sdrb_batch_destroy(h_); }
 
     // Packs the SDRs of [first, last) by iterating each one (the portable way to read any
@@ -389,6 +391,87 @@ class SDRBatch {
     Elements ore(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_OR, db, flags, stream); }
     Elements xore(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_XOR, db, flags, stream); }
     Elements rme(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return elem_op(SDRB_OP_RM, db, flags, stream); }
+
+    // The same rows under another payload type, sharing this batch's offsets and ids on the device (the view must
+    // not outlive *this, nor an upload into it).  ids_only: payloads dropped.  as_unit (EmptyData batches): every
+    // element carries UnitData(EmptyData) = 1 (UnitData.hpp:13-14, SDRElem.hpp:29-30).  Batches of 32-bit ids.
+    SDRBatch ids_only() const { return view(SDRB_DATA_EMPTY, nullptr); }
+    SDRBatch as_unit(void* stream = nullptr) const {
+        if (kind_ != SDRB_DATA_EMPTY) throw Error(SDRB_ERR_INVALID_ARG, "as_unit converts EmptyData batches");
+        return view(SDRB_DATA_UNIT, stream);
+    }
+
+    // Element ops with the reference's result-type argument, a.ande<ret_t, c_ret_t>(b) (SDR.hpp:151-152, 209-212,
+    // 237-240, 292-293).  ret = SDRB_DATA_EMPTY: a match's data is converted to EmptyData before its relevance is
+    // asked, so payloads play no part (EmptyData.hpp:27-37: intersections keep every common id, xore and rme drop
+    // every common id).  ret = SDRB_DATA_UNIT on an EmptyData `this`: a match gets EmptyData::op<UnitData>() =
+    // UnitData() = 1 and is kept (EmptyData.hpp:44-45, 53-54, 64-65), elements of `this` alone become
+    // UnitData(EmptyData) = 1, elements of the argument alone keep their payload -- for ore and for xore alike;
+    // rme has no such form (EmptyData::rme returns EmptyData whatever is asked for, EmptyData.hpp:73-74).
+    // ret = this batch's own kind: the plain op.
+    Elements elem_op_as(int ret, int op, const SDRBatch& db, void* stream = nullptr) const {
+        if (ret == kind_) return elem_op(op, db, 0, stream);
+        if (ret == SDRB_DATA_EMPTY) {
+            const SDRBatch mine = ids_only(), theirs = db.ids_only();
+            Elements e = mine.elem_op(op, theirs, 0, stream);
+            check(sdrb_stream_sync(device_, stream));   // the views end here
+            return e;
+        }
+        if (ret != SDRB_DATA_UNIT || kind_ != SDRB_DATA_EMPTY)
+            throw Error(SDRB_ERR_UNSUPPORTED, "result types: EmptyData from any batch, UnitData from an EmptyData or UnitData batch");
+        if (op == SDRB_OP_RM) throw Error(SDRB_ERR_UNSUPPORTED, "rme of an EmptyData batch yields EmptyData whatever result type is asked for");
+        if (op == SDRB_OP_AND) {
+            const SDRBatch theirs = db.ids_only();
+            Elements e = elem_op(op, theirs, 0, stream);
+            check(sdrb_stream_sync(device_, stream));
+            const std::vector<float> ones(e.total ? e.total : 1, 1.0f);
+            e.data = detail::DeviceBuffer(db.device_, ones.size() * sizeof(float));
+            check(sdrb_memcpy_h2d(db.device_, e.data.ptr, ones.data(), ones.size() * sizeof(float), stream));
+            e.has_data = true;
+            return e;
+        }
+        const SDRBatch mine = as_unit(stream);
+        Elements e = mine.elem_op(SDRB_OP_OR, db, 0, stream);
+        check(sdrb_stream_sync(device_, stream));
+        return e;
+    }
+
+    // rmi with the reference's rmi_combiner (SDR.hpp:304-310, 1447-1513), row by row: for every id that row j of
+    // *this shares with row j of arg, the element's payload becomes combine(this_value, arg_value) -- arg_value is
+    // a null pointer when arg is EmptyData -- and the element is removed when the new payload is not rm_relevant
+    // (UnitData: below 0.1, UnitData.hpp:22-28; ArithData: never, ArithData.hpp:22-28); other elements stay.  The
+    // combiner runs on the host over the matches andv reports (ascending ids within a row).  Batches of 32-bit ids.
+    template <typename Combine>
+    SDRBatch& rmi(const SDRBatch& arg, Combine combine, void* stream = nullptr) {
+        if (kind_ == SDRB_DATA_EMPTY) throw Error(SDRB_ERR_INVALID_ARG, "a combiner needs payloads on this batch");
+        if (id_bits_ != 32 || arg.id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "rmi with a combiner serves batches of 32-bit ids");
+        const Visits::Host hits = visit(SDRB_VISIT_AND, arg, SDRB_FLAG_ROWWISE, stream).to_host(stream);
+        Elements::Host mine = to_host(stream);
+        Elements::Host theirs;
+        if (arg.kind_ != SDRB_DATA_EMPTY) theirs = arg.to_host(stream);
+        std::vector<char> keep(mine.ids.size(), 1);
+        for (size_t j = 0; j < n_rows_; ++j)
+            for (uint32_t k = hits.offsets[j]; k < hits.offsets[j + 1]; ++k) {
+                const size_t at = mine.offsets[j] + hits.this_pos[k];
+                const float* arg_value = theirs.data.empty() ? nullptr : &theirs.data[theirs.offsets[j] + hits.arg_pos[k]];
+                const float v = combine(mine.data[at], arg_value);
+                mine.data[at] = v;
+                if (kind_ == SDRB_DATA_UNIT && !(v >= 0.1f)) keep[at] = 0;   // binary32 compare: the reference's double compare gives the same verdict
+            }
+        std::vector<uint64_t> off{0};
+        std::vector<int32_t> ids;
+        std::vector<float> data;
+        for (size_t j = 0; j < n_rows_; ++j) {
+            for (uint32_t k = mine.offsets[j]; k < mine.offsets[j + 1]; ++k)
+                if (keep[k]) {
+                    ids.push_back((int32_t)mine.ids[k]);
+                    data.push_back(mine.data[k]);
+                }
+            off.push_back(ids.size());
+        }
+        check(sdrb_batch_upload_csr(h_, n_rows_, off.data(), ids.data(), data.empty() ? nullptr : data.data(), stream));
+        return *this;
+    }
 
     // The same four results when they may exceed 2^32-1 elements (e.g. 64 rows of 328 ids in union with 128 Ki
     // such rows): the rows of *this are cut into consecutive ranges whose results fit, one CSR each.  op is
@@ -559,6 +642,29 @@ class SDRBatch {
     }
 
  private:
+    SDRBatch view(int kind, void* stream) const {
+        if (id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "views exist for batches of 32-bit ids");
+        const uint32_t* d_off = nullptr;
+        const int32_t* d_ids = nullptr;
+        const float* d_data = nullptr;
+        uint64_t nnz = 0;
+        uint32_t max_len = 0;
+        int32_t width = 0, lo_id = 0, hi_id = -1;
+        check(sdrb_batch_device_ptrs(h_, &d_off, &d_ids, &d_data));
+        check(sdrb_batch_info(h_, nullptr, nullptr, &nnz, &width, nullptr, &max_len));
+        check(sdrb_batch_id_span(h_, &lo_id, &hi_id));
+        SDRBatch v(device_, width, kind);
+        const float* payloads = nullptr;
+        if (kind != SDRB_DATA_EMPTY) {
+            const std::vector<float> ones(nnz ? nnz : 1, 1.0f);
+            v.view_data_ = detail::DeviceBuffer(device_, ones.size() * sizeof(float));
+            check(sdrb_memcpy_h2d(device_, v.view_data_.ptr, ones.data(), ones.size() * sizeof(float), stream));
+            payloads = static_cast<const float*>(v.view_data_.ptr);
+        }
+        check(sdrb_batch_adopt_device_csr(v.h_, n_rows_, nnz, d_off, d_ids, payloads, max_len, lo_id, hi_id));
+        v.n_rows_ = n_rows_;
+        return v;
+    }
     Counts size_op(int op, const SDRBatch& db, unsigned flags, void* stream) const {
         Counts c(db.device_, n_rows_, db.n_rows_);
         check(sdrb_size_op(h_, db.h_, op, flags, c.device_ptr(), db.n_rows_, stream));
@@ -573,6 +679,7 @@ class SDRBatch {
         e.has_data = self.kind_ != SDRB_DATA_EMPTY;
         e.id_bits = id_bits_;
         e.offsets = detail::DeviceBuffer(db.device_, (e.na * e.nb + 1) * sizeof(uint32_t));
+        if (!rowwise && id_bits_ == 32 && db.id_bits_ == 32 && elem_op_one_enqueue(op, db, flags, stream, &e)) return e;
         check(sdrb_elem_op_count(h_, db.h_, op, flags, static_cast<uint32_t*>(e.offsets.ptr), &e.total, stream));
         e.ids = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * (id_bits_ / 8));
         if (e.has_data) e.data = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * sizeof(float));
@@ -584,6 +691,53 @@ class SDRBatch {
                                     static_cast<int32_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
         }
         return e;
+    }
+    // Count, scan and fill enqueued back to back, the element arrays sized from the shapes (sdrb_elem_op), or, for
+    // ande of a few rows against a sparse database, from the expected number of matches (sdrb_ande_few; a result
+    // that outgrows the estimate is computed again with room).  The host waits once, for the element total.
+    // false: the shapes do not allow it (the caller falls back to the two-call protocol).
+    bool elem_op_one_enqueue(int op, const SDRBatch& db, unsigned flags, void* stream, Elements* e) const {
+        uint64_t bound = 0;
+        if (sdrb_elem_op_bound(h_, db.h_, op, flags, &bound) != SDRB_OK || bound > 0xFFFFFFFFull) return false;
+        uint64_t a_nnz = 0, b_nnz = 0;
+        int32_t b_width = 0;
+        uint32_t b_longest = 0;
+        check(sdrb_batch_info(h_, nullptr, nullptr, &a_nnz, nullptr, nullptr, nullptr));
+        check(sdrb_batch_info(db.h_, nullptr, nullptr, &b_nnz, &b_width, nullptr, &b_longest));
+        const bool few = op == SDRB_OP_AND && n_rows_ >= 1 && n_rows_ <= 32 && b_width > 0 && b_width <= 4096 &&
+                         b_longest <= 64 && (flags & ~SDRB_FLAG_SWAP) == 0;
+        // ande of dense rows has a bound far above its result: only the estimate-sized call pays there
+        if (op == SDRB_OP_AND && !few && bound > (64ull << 20)) return false;
+        detail::DeviceBuffer total_dev(db.device_, sizeof(uint64_t));
+        uint64_t capacity = bound ? bound : 1;
+        if (few) {
+            const double expected = (double)a_nnz * (double)b_nnz / (double)b_width;
+            const uint64_t estimate = (uint64_t)(expected * 1.3 + 8.0 * std::sqrt(expected)) + 4096;
+            if (estimate < capacity) capacity = estimate;
+        }
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            e->ids = detail::DeviceBuffer(db.device_, capacity * sizeof(int32_t));
+            if (e->has_data) e->data = detail::DeviceBuffer(db.device_, capacity * sizeof(float));
+            int rc = SDRB_ERR_UNSUPPORTED;
+            if (few)
+                rc = sdrb_ande_few(h_, db.h_, flags, static_cast<uint32_t*>(e->offsets.ptr), static_cast<int32_t*>(e->ids.ptr),
+                                   static_cast<float*>(e->data.ptr), capacity, static_cast<uint64_t*>(total_dev.ptr), stream);
+            if (rc == SDRB_ERR_UNSUPPORTED) {
+                if (capacity < bound) {   // the few-rows kernel declined: the general one needs the full bound
+                    capacity = bound;
+                    e->ids = detail::DeviceBuffer(db.device_, capacity * sizeof(int32_t));
+                    if (e->has_data) e->data = detail::DeviceBuffer(db.device_, capacity * sizeof(float));
+                }
+                rc = sdrb_elem_op(h_, db.h_, op, flags, static_cast<uint32_t*>(e->offsets.ptr), static_cast<int32_t*>(e->ids.ptr),
+                                  static_cast<float*>(e->data.ptr), capacity, static_cast<uint64_t*>(total_dev.ptr), stream);
+                if (rc == SDRB_ERR_UNSUPPORTED) return false;
+            }
+            check(rc);
+            e->total = total_dev.to_host<uint64_t>(1, stream)[0];
+            if (e->total <= capacity) return true;
+            capacity = e->total;   // the estimate was too small: once more, with room
+        }
+        throw std::runtime_error("sdr_amd: element total changed between two runs of one operation");
     }
     Visits visit(int which, const SDRBatch& db, unsigned flags, void* stream) const {
         Visits v;
@@ -612,6 +766,7 @@ class SDRBatch {
     size_t n_rows_ = 0;
     int kind_ = SDRB_DATA_EMPTY;
     int id_bits_ = 32;
+    detail::DeviceBuffer view_data_;   // a view's own payloads (as_unit)
 };
 
 }  // namespace sdr_amd

@@ -101,6 +101,90 @@ int run(const char* name, std::mt19937& rng, int width, int32_t declared_width) 
     return 0;
 }
 
+// ande of a few rows of `this` against a database (the one-enqueue path sized by an estimate): every pair equals the
+// reference's ande; with `copies` the database repeats the queries' rows, so the result outgrows the estimate and
+// is computed a second time with room.
+template <typename A>
+int run_few(const char* name, std::mt19937& rng, int width, int len, bool copies) {
+    auto qs = make_rows<A>(rng, 5, width, len);
+    auto ds = make_rows<A>(rng, 301, width, len);
+    if (copies)
+        for (size_t j = 0; j < ds.size(); ++j) ds[j] = qs[j % qs.size()];
+    auto q = sdr_amd::SDRBatch::pack(qs.begin(), qs.end(), 0, width);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, width);
+    using R = SDR<typename A::value_type, std::vector<typename A::value_type>>;
+    auto e = q.ande(d);
+    auto h = e.to_host();
+    auto e_sw = d.ande(q, SDRB_FLAG_SWAP);   // this = the argument batch: result (j, i) = qs[i].ande(ds[j])
+    auto h_sw = e_sw.to_host();
+    uint64_t total = 0;
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            const R want = qs[i].ande(ds[j]);
+            total += want.size();
+            REQUIRE(sdr_amd::Elements::unpack<R>(h, ds.size(), i, j) == want);
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_sw, qs.size(), j, i) == want);
+        }
+    REQUIRE(e.total == total && e_sw.total == total);
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
+// Result types other than this's own, a.ande<ret_t, c_ret_t>(b) of the reference (SDR.hpp:151-152, 209-212,
+// 237-240, 292-293), pair by pair against the reference's own template instantiations.
+template <typename A, typename B, typename RetElem, bool kWithRme>
+int run_retarget(const char* name, std::mt19937& rng, int ret_kind) {
+    auto qs = make_rows<A>(rng, 23, 200, 40);
+    auto ds = make_rows<B>(rng, 150, 200, 40);
+    auto q = sdr_amd::SDRBatch::pack(qs.begin(), qs.end(), 0, 200);
+    auto d = sdr_amd::SDRBatch::pack(ds.begin(), ds.end(), 0, 200);
+    using R = SDR<RetElem, std::vector<RetElem>>;
+    auto h_and = q.elem_op_as(ret_kind, SDRB_OP_AND, d).to_host();
+    auto h_or = q.elem_op_as(ret_kind, SDRB_OP_OR, d).to_host();
+    auto h_xor = q.elem_op_as(ret_kind, SDRB_OP_XOR, d).to_host();
+    for (size_t i = 0; i < qs.size(); ++i)
+        for (size_t j = 0; j < ds.size(); ++j) {
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_and, ds.size(), i, j) == (qs[i].template ande<RetElem, std::vector<RetElem>>(ds[j])));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_or, ds.size(), i, j) == (qs[i].template ore<RetElem, std::vector<RetElem>>(ds[j])));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_xor, ds.size(), i, j) == (qs[i].template xore<RetElem, std::vector<RetElem>>(ds[j])));
+        }
+    // an EmptyData `this` has no rme into UnitData: EmptyData::rme returns EmptyData, the reference does not compile it
+    if constexpr (kWithRme) {
+        auto h_rm = q.elem_op_as(ret_kind, SDRB_OP_RM, d).to_host();
+        for (size_t i = 0; i < qs.size(); ++i)
+            for (size_t j = 0; j < ds.size(); ++j)
+                REQUIRE(sdr_amd::Elements::unpack<R>(h_rm, ds.size(), i, j) == (qs[i].template rme<RetElem, std::vector<RetElem>>(ds[j])));
+    }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
+// rmi with a caller's combiner (SDR.hpp:304-310, 1447-1513): the same lambda body handed to the reference row by row
+template <typename A, typename B>
+int run_rmi_combiner(const char* name, std::mt19937& rng) {
+    auto as = make_rows<A>(rng, 120, 150, 40);
+    auto bs = make_rows<B>(rng, 120, 150, 40);
+    auto a = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 150);
+    auto b = sdr_amd::SDRBatch::pack(bs.begin(), bs.end(), 0, 150);
+    constexpr bool arg_has_value = sdr_amd::detail::has_value<typename B::value_type::data_type>::value;
+    a.rmi(b, [](float mine, const float* theirs) { return theirs ? mine * (1.0f - *theirs * 0.5f) : mine * 0.5f; });
+    auto h = a.to_host();
+    for (size_t j = 0; j < as.size(); ++j) {
+        A want = as[j];
+        want.rmi(bs[j], [](typename A::iterator this_pos, typename B::iterator arg_pos) {
+            auto& mine = const_cast<typename A::value_type::data_type&>(this_pos->data());
+            float v;
+            if constexpr (arg_has_value) v = mine.value() * (1.0f - arg_pos->data().value() * 0.5f);
+            else v = mine.value() * 0.5f;
+            (void)arg_pos;
+            mine = typename A::value_type::data_type(v);
+        });
+        REQUIRE(sdr_amd::Elements::unpack<A>(h, 1, j, 0) == want);
+    }
+    std::printf("ok %-28s %ld checks so far\n", name, g_checks);
+    return 0;
+}
+
 // all-pairs top-k of a database with itself: every count is the reference's ands, the order is
 // overlap descending then row ascending, the self match is excluded
 int run_allpairs(std::mt19937& rng, unsigned flags, const char* name) {
@@ -439,6 +523,15 @@ int main() {
         if (run<SDR<LE>, SDR<LE>>("long ids", rng, 512, 0)) return 1;
         if (run<SDR<LU>, SDR<LU>>("long ids, unit x unit", rng, 200, 0)) return 1;
         if (run<SDR<LU>, SDR<LE>>("long ids, unit x empty", rng, 200, 0)) return 1;
+        if (run_few<SDR<E>>("few rows, ande", rng, 512, 40, false)) return 1;
+        if (run_few<SDR<U>>("few rows, ande, unit", rng, 300, 40, false)) return 1;
+        if (run_few<SDR<U>>("few rows, ande, refill", rng, 64, 40, true)) return 1;
+        if (run_retarget<SDR<U>, SDR<U>, E, true>("unit x unit -> empty", rng, SDRB_DATA_EMPTY)) return 1;
+        if (run_retarget<SDR<U>, SDR<E>, E, true>("unit x empty -> empty", rng, SDRB_DATA_EMPTY)) return 1;
+        if (run_retarget<SDR<E>, SDR<U>, U, false>("empty x unit -> unit", rng, SDRB_DATA_UNIT)) return 1;
+        if (run_retarget<SDR<E>, SDR<E>, U, false>("empty x empty -> unit", rng, SDRB_DATA_UNIT)) return 1;
+        if (run_rmi_combiner<SDR<U>, SDR<U>>("rmi combiner unit x unit", rng)) return 1;
+        if (run_rmi_combiner<SDR<U>, SDR<E>>("rmi combiner unit x empty", rng)) return 1;
         if (run_inner<SDR<AE>>(rng, "inner arith x arith")) return 1;
         if (run_inner<SDR<E>>(rng, "inner arith x empty")) return 1;
         if (run_inplace<SDR<E>, SDR<E>>(rng, "in-place empty x empty")) return 1;
