@@ -175,17 +175,13 @@ __global__ __launch_bounds__(kBlock, 3) void k_lane_rows_inner(
 // What is counted, and what leaves the kernel (dropped = matches - kept):
 //   kCountKept     ands = kept                                      (SDR.hpp:1083-1095)
 //   kCountDropped  rms  = |this| - dropped                          (SDR.hpp:1572-1576)
-//   kCountBoth     xors = |this| + |arg| - (matches + dropped)      (SDR.hpp:1428-1433): the masks counted beside the dropped words
+//   kCountBoth     xors = |this| + |arg| - (matches + dropped)      (SDR.hpp:1428-1433): the masks counted in a pass of their own
 enum Count { kCountKept, kCountDropped, kCountBoth };
-// waves a SIMD: with payloads on both sides and two counters (xors of two UnitData batches) three waves' registers
-// do not hold a lane's row, its payloads and the tile in flight (45 spilled; 10.5 ms at 4096 x 1 Mi against 8.2 ms)
-template <int MATH, int COUNT>
-constexpr int kSizeWaves = (COUNT == kCountBoth && MATH != kSelfA && MATH != kSelfB) ? 2 : 3;
 constexpr uint32_t lane_tile_cap(uint32_t wcap) {   // the largest tile: rows of A of kMaxRowA ids
     return mask_bytes(wcap) + col_bytes(wcap) + (uint32_t)kTile * kMaxRowA * 4u + kLenBytes;
 }
 template <int MATH, int COUNT, int NCH, int WCAP, int PF>
-__global__ __launch_bounds__(kBlock, (kSizeWaves<MATH, COUNT>)) void k_lane_rows_size(
+__global__ __launch_bounds__(kBlock, 3) void k_lane_rows_size(
     const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, const float* __restrict__ b_val,
     uint64_t nb, const unsigned char* __restrict__ tables, uint32_t tile_bytes, uint32_t ntiles,
     uint32_t tiles_per_block, uint32_t na, uint32_t la_coef, uint32_t lb_coef,
@@ -275,7 +271,34 @@ __global__ __launch_bounds__(kBlock, (kSizeWaves<MATH, COUNT>)) void k_lane_rows
                 if (tid + p * kBlock < nvec) piece[p] = src[tid + p * kBlock];
         }
 
-        uint32_t planes[NPL], mask_planes[NPL];   // mask_planes: the id matches, counted for xors only
+        uint32_t planes[NPL];
+        uint32_t match_of[8];   // xors only: the id matches of the 32 rows, four byte-wide counts a word
+        if constexpr (COUNT == kCountBoth) {
+            // the masks themselves are counted first, in a pass of their own, and unpacked; the fence keeps the compiler
+            // from carrying all forty masks over to the payload pass in registers
+            uint32_t mask_planes[NPL];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                uint32_t m[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    uint32_t pair = idp[ch * 4 + k2];
+                    asm volatile("" : "+v"(pair));
+                    m[2 * k2] = *reinterpret_cast<const uint32_t*>(tab + (pair & 0xffffu));
+                    m[2 * k2 + 1] = *reinterpret_cast<const uint32_t*>(tab + (pair >> 16));
+                }
+                if (ch == 0) add8<NPL, true>(mask_planes, m);
+                else add8<NPL, false>(mask_planes, m);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint32_t y = 0;
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) y |= rotr32(mask_planes[p], r - p) & (0x01010101u << p);
+                match_of[r] = y;
+            }
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             // the tile is a plain array to the compiler, its loads free to move: all forty masks would be fetched
@@ -291,10 +314,6 @@ __global__ __launch_bounds__(kBlock, (kSizeWaves<MATH, COUNT>)) void k_lane_rows
                 m[2 * k2 + 1] = *reinterpret_cast<const uint32_t*>(tab + o1);
                 kp[2 * k2] = kNeedA ? *reinterpret_cast<const uint16_t*>(tab + COL_AT + (o0 >> 1)) : 0u;
                 kp[2 * k2 + 1] = kNeedA ? *reinterpret_cast<const uint16_t*>(tab + COL_AT + (o1 >> 1)) : 0u;
-            }
-            if constexpr (COUNT == kCountBoth) {
-                if (ch == 0) add8<NPL, true>(mask_planes, m);
-                else add8<NPL, false>(mask_planes, m);
             }
             constexpr bool kWantKept = COUNT == kCountKept;   // the words collect kept matches, else dropped ones
             float d;
@@ -357,12 +376,7 @@ __global__ __launch_bounds__(kBlock, (kSizeWaves<MATH, COUNT>)) void k_lane_rows
             uint32_t x = 0;
 #pragma unroll
             for (int p = 0; p < NPL; ++p) x |= rotr32(planes[p], r - p) & (0x01010101u << p);
-            if constexpr (COUNT == kCountBoth) {   // four byte-wide sums at once: both counts stay below 128
-                uint32_t y = 0;
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) y |= rotr32(mask_planes[p], r - p) & (0x01010101u << p);
-                x += y;
-            }
+            if constexpr (COUNT == kCountBoth) x += match_of[r];   // four byte-wide sums at once: both counts stay below 128
             count_of[r] = x;
         }
         uint32_t la_vec = 0;
