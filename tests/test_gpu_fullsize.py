@@ -155,3 +155,34 @@ def test_few_unit_queries_against_full_database():
                 assert np.array_equal(r_ids[int(r_off[p]):int(r_off[p + 1])], w_ids[int(w_off[w]):int(w_off[w + 1])])
                 assert np.array_equal(r_data[int(r_off[p]):int(r_off[p + 1])].view(np.uint32),
                                       w_data[int(w_off[w]):int(w_off[w + 1])].view(np.uint32))
+
+
+def test_many_unit_queries_against_full_database(problem):
+    """UnitData on both sides, 1024 queries x 1 Mi rows: the lane-per-row size kernel with its tiles shared over
+    blocks, every tile and block boundary of the full length.  ands / xors / rms equal the oracle on 300 sampled
+    rows of the database for all queries; everywhere, a payload can only remove a match from ands and can only
+    keep one in xors and rms, so each result lies on its side of the id-only result of the same pair."""
+    import torch
+    _, _, _, _, out = problem
+    nq = 1024
+    q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE, True)
+    d_csr = sdr_amd.synth_csr(1, 0, ND, WIDTH, ACTIVE, True)
+    q = SDRBatch.from_csr(*q_csr, width=WIDTH)
+    d = SDRBatch.from_csr(*d_csr, width=WIDTH)
+    q_ids = SDRBatch.from_csr(q_csr[0], q_csr[1], width=WIDTH)
+    d_ids = SDRBatch.from_csr(d_csr[0], d_csr[1], width=WIDTH)
+    rng = np.random.default_rng(23)
+    rows = np.sort(rng.choice(ND, 300, replace=False))
+    off, ids, data = d_csr
+    lens = (off[rows + 1] - off[rows]).astype(np.int64)
+    sub_d = Batch(np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64),
+                  np.concatenate([ids[int(off[r]):int(off[r + 1])] for r in rows]),
+                  np.concatenate([data[int(off[r]):int(off[r + 1])] for r in rows]))
+    oq = Batch(*q_csr)
+    cols = torch.from_numpy(rows).cuda()
+    got, plain = out[:nq], torch.empty((nq, ND), dtype=torch.int32, device="cuda:0")
+    for op, name in ((0, "ands"), (2, "xors"), (3, "rms")):
+        getattr(q, name)(d, out=got)
+        assert np.array_equal(got[:, cols].cpu().numpy().view(np.uint32), oracle.port().size_op(op, oq, sub_d)), name
+        getattr(q_ids, name)(d_ids, out=plain)
+        assert bool((got <= plain).all() if op == 0 else (got >= plain).all()), name
