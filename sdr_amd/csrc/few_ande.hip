@@ -7,7 +7,8 @@
 // (write, scan, read again) than on finding the matches.  Here a lane owns one row of B (ids and payloads in
 // registers) and walks it against the 32-row tile tables of A in LDS (lane_tiles.h), as in lane_rows.hip, and
 //
-//   (1) k_few_ande_count : walk; per pair the number of kept matches as ONE BYTE (a row of B holds at most 64 ids),
+//   (1) k_few_ande_count : per pair the number of kept matches (bit-sliced counters in registers) as ONE BYTE (a row
+//                          of B holds at most 64 ids),
 //                          per (row of A, 256-row group of B) their sum;
 //   (2) k_few_ande_scan  : one workgroup scans the group sums (na x groups values) in pair order and leaves the
 //                          element total in device memory;
@@ -22,6 +23,7 @@
 #include "lane_tiles.h"
 #include "match_math.h"
 #include "sdrb_internal.h"
+#include "vertical_counters.h"
 
 namespace sdrb {
 
@@ -129,19 +131,84 @@ __device__ __forceinline__ void walk(const unsigned char* tab, uint32_t col_at, 
     }
 }
 
+// The number of kept matches of the lane's row with each of the tile's 32 rows, as bit-sliced counters: an id's
+// kept matches are a word with a bit per row of A -- the mask itself where ids alone decide, else the lowest row tested
+// without a branch and further rows in a second step, as in lane_rows.hip -- and eight words at a time go into the
+// vertical counter.  Returns the counts as bytes: count of row q = byte q / 8 of word q % 8.
+template <int MATH, int NCH>
+__device__ __forceinline__ void count_rows(const unsigned char* tab, uint32_t col_at, const uint32_t (&id)[8 * NCH],
+                                           const float (&val)[8 * NCH], uint32_t (&count_of)[8]) {
+    constexpr int NPL = bits_for(8 * NCH);
+    static_assert(NPL <= 8, "counts must fit one byte");
+    uint32_t planes[NPL];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        uint32_t m[8], kp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t o = id[ch * 8 + k];
+            m[k] = *reinterpret_cast<const uint32_t*>(tab + o);
+            kp[k] = need_a<MATH>() ? *reinterpret_cast<const uint16_t*>(tab + col_at + (o >> 1)) : 0u;
+        }
+        float d;
+        if constexpr (MATH == kKeepAll) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) kp[k] = m[k];
+        } else if constexpr (!need_a<MATH>()) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) kp[k] = match_kept_by<MATH>(0.0f, val[ch * 8 + k], d) ? m[k] : 0u;
+        } else {
+            uint32_t rest[8], cc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cc[k] = kp[k];
+                kp[k] = m[k] & (0u - m[k]);
+                rest[k] = m[k] ^ kp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float a0 = *reinterpret_cast<const float*>(tab + cc[k]);
+                kp[k] = match_kept_by<MATH>(a0, val[ch * 8 + k], d) ? kp[k] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t mm = rest[k];
+                if (mm != 0) {
+                    const float bv = val[ch * 8 + k];
+                    uint32_t at = cc[k] + 4, word = kp[k];
+                    while (mm != 0) {
+                        const uint32_t low = mm & (0u - mm);
+                        mm ^= low;
+                        word |= match_kept_by<MATH>(*reinterpret_cast<const float*>(tab + at), bv, d) ? low : 0u;
+                        at += 4;
+                    }
+                    kp[k] = word;
+                }
+            }
+        }
+        if (ch == 0) add8<NPL, true>(planes, kp);
+        else add8<NPL, false>(planes, kp);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) x |= rotr32(planes[p], r - p) & (0x01010101u << p);
+        count_of[r] = x;
+    }
+}
+
 // (1) bytes per pair and sums per (row of A, group of B)
 template <int MATH, int NCH>
 __global__ __launch_bounds__(kBlock) void k_few_ande_count(
     const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, const float* __restrict__ b_val, uint32_t nb,
     const unsigned char* __restrict__ tables, uint32_t tile_bytes, uint32_t wcap, uint32_t na,
     uint8_t* __restrict__ cnt8, uint32_t* __restrict__ group_total, uint32_t n_groups) {
-    // LDS: the tile's tables | acc[na][256] | wave_part[na][4]
+    // LDS: the tile's tables | (acc[na][256], used by the fill only) | wave_part[na][4]
     extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* acc_lane = reinterpret_cast<uint32_t*>(few_lds + tile_bytes) + tid;
     uint32_t* wave_part = reinterpret_cast<uint32_t*>(few_lds + tile_bytes) + na * kBlock;
     stage_tile(few_lds, tables, tile_bytes, tid);
-    for (uint32_t q = 0; q < na; ++q) acc_lane[q * kBlock] = 0u;
     __syncthreads();
     const uint32_t col_at = mask_bytes(wcap);
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -149,13 +216,14 @@ __global__ __launch_bounds__(kBlock) void k_few_ande_count(
         uint32_t id[8 * NCH], lb;
         float val[8 * NCH];
         load_row<NCH, need_b<MATH>()>(b_off, b_ids, b_val, nb, j0, tid, wcap, id, val, lb);
-        walk<MATH, NCH>(few_lds, col_at, id, val, [&](uint32_t q, uint32_t, float) {
-            uint32_t* slot = acc_lane + q * kBlock;
-            *slot = *slot + 1u;
-        });
+        uint32_t count_of[8];
+        count_rows<MATH, NCH>(few_lds, col_at, id, val, count_of);
+        // (the loop stays rolled: the word and the byte of row q are picked by shifts of q)
         for (uint32_t q = 0; q < na; ++q) {
-            const uint32_t c = acc_lane[q * kBlock];
-            acc_lane[q * kBlock] = 0u;
+            uint32_t word = count_of[0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) word = (q & 7u) == (uint32_t)r ? count_of[r] : word;
+            const uint32_t c = (word >> (8u * (q >> 3))) & 0xffu;
             if (j < nb) cnt8[(uint64_t)q * nb + j] = (uint8_t)c;
             const uint32_t incl = wave_inclusive_scan(c);
             if (lane == 63) wave_part[q * kWaves + wave] = incl;
@@ -183,9 +251,19 @@ __global__ __launch_bounds__(kScanThreads) void k_few_ande_scan(uint32_t* __rest
     __shared__ uint32_t part32[kScanThreads / 64];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // elements of the rows of A before this one
+    // (eight loads in flight per thread: one at a time, the 60 round trips of the last row's workgroup were the
+    // kernel's whole duration)
     unsigned long long before = 0;
     const uint64_t n_before = (uint64_t)q * n_groups;
-    for (uint64_t k = tid; k < n_before; k += kScanThreads) before += group_total[k];
+    uint64_t k = tid;
+    for (; k + 7ull * kScanThreads < n_before; k += 8ull * kScanThreads) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = group_total[k + (uint64_t)u * kScanThreads];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) before += v[u];
+    }
+    for (; k < n_before; k += kScanThreads) before += group_total[k];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += (unsigned long long)__shfl_xor((long long)before, d, 64);
     if (lane == 0) part64[wave] = before;
