@@ -542,7 +542,9 @@ bool size_lane_rows_applicable(const sdrb_batch* a, const sdrb_batch* b, int op,
     // against the mask-table kernel: rows of B of at most 40 ids (longer rows leave a lane no registers for the tile
     // in flight; measured at 4096/64: 1.38 against 1.03 ms) -- then it wins from 0.16 to 5 rows of a tile per id
     // (1024 x 256 Ki rows of 40 ids at widths 4096 ... 256: 0.48 / 0.59, 0.48 / 0.81, 0.56 / 0.92, 0.72 / 1.10, 1.00 / 1.56 ms)
-    return forced || (a->n_rows > 16 && b->max_row_len <= 40 && sparse_enough(a, b, 50));
+    // and against the few-rows kernel of mask_table.hip from two rows of A on (1 Mi rows of B, 2048/40, ands: 2 rows 78 / 84,
+    // 8 rows 89 / 104, 16 rows 101 / 132 us; one row: 76 / 81 us for ands but 87 / 80 us for xors)
+    return forced || (a->n_rows >= 2 && b->max_row_len <= 40 && sparse_enough(a, b, 50));
 }
 
 int launch_size_lane_rows(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out, uint64_t ld_out,

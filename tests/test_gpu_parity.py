@@ -576,6 +576,9 @@ def test_few_rows_of_a_size_kernels_vs_oracle(name, nq, width, len_a, len_b):
     for op in range(4):
         assert np.array_equal(gpu_sizes(op, dt, da), oracle.port().size_op(op, t, a)), op
         assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), op
+        # the mask-table family's own few-rows kernel, whatever the default choice is
+        assert np.array_equal(gpu_sizes(op, dt, da, algo="masktable"), oracle.port().size_op(op, t, a)), op
+        assert np.array_equal(gpu_sizes(op, dt, da, swap=True, algo="masktable"), oracle.port().size_op(op, a, t).T), op
     assert_elems_equal(gpu_elems(AND, dt, da), oracle.port().elem_op(AND, t, a))
     off, ids, data = gpu_elems(AND, dt, da, swap=True)
     w_off, w_ids, w_data = oracle.port().elem_op(AND, a, t)
