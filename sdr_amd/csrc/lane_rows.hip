@@ -301,9 +301,6 @@ __global__ __launch_bounds__(kBlock, 3) void k_lane_rows_size(
         }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            // the tile is a plain array to the compiler, its loads free to move: all forty masks would be fetched
-            // ahead and sit in registers; a chunk's loads stay in the chunk
-            asm volatile("" ::: "memory");
             uint32_t m[8], kp[8];
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) {
