@@ -394,12 +394,14 @@ def secondary_configs(dev) -> dict:
     d_csr = sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE, True)
     q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE, True)
     d, q = SDRBatch.from_csr(*d_csr, width=WIDTH), SDRBatch.from_csr(*q_csr, width=WIDTH)
-    ms, _ = _timed(lambda: q.ands(d, out=out_buf), reps=3)
-    want = oracle.port().size_op(oracle.AND, oracle.Batch(*rows_with(q_csr, qi, q_csr[2])), oracle.Batch(*rows_with(d_csr, dj, d_csr[2])))
-    got = out_buf[torch.as_tensor(qi, device=dev)][:, torch.as_tensor(dj, device=dev)].cpu().numpy().view(np.uint32)
     nbytes = (nd + nq) * (8 * ACTIVE + 4) + nq * nd * 4
-    out["unit_ands_4096"] = line(ms, nbytes, bool(np.array_equal(got, want)),
-                                 workload=f"ands: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, UnitData on both sides")
+    sub_q, sub_d = oracle.Batch(*rows_with(q_csr, qi, q_csr[2])), oracle.Batch(*rows_with(d_csr, dj, d_csr[2]))
+    for name, op in (("ands", oracle.AND), ("xors", oracle.XOR), ("rms", oracle.RM)):
+        ms, _ = _timed(lambda: getattr(q, name)(d, out=out_buf), reps=3)
+        want = oracle.port().size_op(op, sub_q, sub_d)
+        got = out_buf[torch.as_tensor(qi, device=dev)][:, torch.as_tensor(dj, device=dev)].cpu().numpy().view(np.uint32)
+        out[f"unit_{name}_4096"] = line(ms, nbytes, bool(np.array_equal(got, want)),
+                                        workload=f"{name}: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, UnitData on both sides")
     del d, q
     q_val = rng.standard_normal(q_csr[1].size).astype(np.float32)
     d_val = rng.standard_normal(d_csr[1].size).astype(np.float32)
