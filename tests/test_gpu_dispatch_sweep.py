@@ -1,0 +1,84 @@
+"""The default kernel choice at its boundaries.  sdrb_size_op / sdrb_elem_op pick a kernel from the shapes -- rows of A
+(1, 2, 8 / 9, 16 / 17, 32 / 33), the longest row of B (40 / 41, 64 / 65), the declared width (2048 / 2049, 4096 / 4097,
+none) and the payload kinds; every such choice has to give the reference's results, so the shapes on either side of each
+threshold are run through the defaults (no algo=...) and compared with the CPU oracle, all four ops, both orientations."""
+import itertools
+
+import numpy as np
+import pytest
+
+import oracle
+import util
+from oracle import AND, Batch
+from sdr_amd import SDRBatch
+
+pytestmark = pytest.mark.gpu
+
+OPS = {0: ("ands", "ande"), 1: ("ors", "ore"), 2: ("xors", "xore"), 3: ("rms", "rme")}
+PAIRINGS = {"EE": (False, False), "UU": (True, True), "UE": (True, False), "EU": (False, True)}
+
+
+def dev(b: Batch, width) -> SDRBatch:
+    return SDRBatch.from_csr(b.off, b.ids, b.data, width=width)
+
+
+def check_sizes(dt, da, t, a, tag):
+    for op in range(4):
+        got = getattr(dt, OPS[op][0])(da).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, oracle.port().size_op(op, t, a)), (tag, OPS[op][0])
+        got = getattr(dt, OPS[op][0])(da, swap=True).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, oracle.port().size_op(op, a, t).T), (tag, OPS[op][0], "swap")
+
+
+def check_elems(dt, da, t, a, tag):
+    for op in range(4):
+        off, ids, data = getattr(dt, OPS[op][1])(da).to_host()
+        w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids), (tag, OPS[op][1])
+        if w_data is None:
+            assert data is None, (tag, OPS[op][1])
+        else:
+            assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), (tag, OPS[op][1])
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("na", [1, 2, 8, 9, 16, 17, 32, 33])
+def test_rows_of_a_thresholds(name, na):
+    tu, au = PAIRINGS[name]
+    for width, len_b in ((2048, 40), (4096, 64)):
+        rng = np.random.default_rng(1000 * na + width + 2 * tu + au)
+        t = Batch(*util.ragged_rows(rng, na, width, 40, tu))
+        a = Batch(*util.ragged_rows(rng, 333, width, len_b, au))
+        dt, da = dev(t, width), dev(a, width)
+        check_sizes(dt, da, t, a, (name, na, width))
+        check_elems(dt, da, t, a, (name, na, width))
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("len_b", [40, 41, 64, 65])
+def test_row_length_thresholds(name, len_b):
+    tu, au = PAIRINGS[name]
+    for na, width in itertools.product((3, 20, 70), (2048, 4096)):
+        rng = np.random.default_rng(77 * len_b + na + width + 2 * tu + au)
+        # rows of exactly the threshold length among shorter ones
+        a_rows = util.ragged_rows(rng, 257, width, len_b, au)
+        t = Batch(*util.ragged_rows(rng, na, width, min(len_b, 128), tu))
+        a = Batch(*a_rows)
+        dt, da = dev(t, width), dev(a, width)
+        check_sizes(dt, da, t, a, (name, len_b, na, width))
+        if na != 70:
+            check_elems(dt, da, t, a, (name, len_b, na, width))
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("width,declared", [(2048, 2048), (2049, 2049), (4096, 4096), (4097, 4097), (17000, 17000),
+                                            (18000, 18000), (28000, 28000), (29000, 29000), (4096, 0)])
+def test_width_thresholds(name, width, declared):
+    tu, au = PAIRINGS[name]
+    for na in (2, 24):
+        rng = np.random.default_rng(width + declared + na + 2 * tu + au)
+        t = Batch(*util.ragged_rows(rng, na, width, 40, tu))
+        a = Batch(*util.ragged_rows(rng, 300, width, 40, au))
+        dt, da = dev(t, declared), dev(a, declared)
+        check_sizes(dt, da, t, a, (name, width, declared, na))
+        check_elems(dt, da, t, a, (name, width, declared, na))
