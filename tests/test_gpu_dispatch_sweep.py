@@ -82,3 +82,21 @@ def test_width_thresholds(name, width, declared):
         dt, da = dev(t, declared), dev(a, declared)
         check_sizes(dt, da, t, a, (name, width, declared, na))
         check_elems(dt, da, t, a, (name, width, declared, na))
+
+
+@pytest.mark.parametrize("na", [1, 8, 9, 40])
+@pytest.mark.parametrize("len_b", [16, 17, 32, 33, 40, 41, 64, 65])
+def test_dot_product_thresholds(na, len_b):
+    """sdrb_inner's default choice (few rows / match-visiting / dense table / per-pair merge) around its thresholds:
+    float bits equal the oracle's, with ArithData and with EmptyData arguments."""
+    for width, declared in ((2048, 2048), (4096, 4096), (4097, 4097), (300, 300), (4096, 0)):
+        rng = np.random.default_rng(31 * na + len_b + width + declared)
+        t_csr = util.arith_rows(rng, na, width, 40)
+        a_csr = util.arith_rows(rng, 270, width, len_b)
+        t = SDRBatch.from_csr(*t_csr, width=declared, kind="arith")
+        a = SDRBatch.from_csr(*a_csr, width=declared, kind="arith")
+        a_ids = SDRBatch.from_csr(a_csr[0], a_csr[1], None, width=declared)
+        want = oracle.port().inner(Batch(*t_csr), Batch(*a_csr)).view(np.uint32)
+        want_e = oracle.port().inner(Batch(*t_csr), Batch(a_csr[0], a_csr[1], None)).view(np.uint32)
+        assert np.array_equal(t.inner(a).cpu().numpy().view(np.uint32), want), (na, len_b, width, declared)
+        assert np.array_equal(t.inner(a_ids).cpu().numpy().view(np.uint32), want_e), (na, len_b, width, declared, "empty arg")
