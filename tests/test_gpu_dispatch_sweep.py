@@ -100,3 +100,35 @@ def test_dot_product_thresholds(na, len_b):
         want_e = oracle.port().inner(Batch(*t_csr), Batch(a_csr[0], a_csr[1], None)).view(np.uint32)
         assert np.array_equal(t.inner(a).cpu().numpy().view(np.uint32), want), (na, len_b, width, declared)
         assert np.array_equal(t.inner(a_ids).cpu().numpy().view(np.uint32), want_e), (na, len_b, width, declared, "empty arg")
+
+
+@pytest.mark.parametrize("top", [2 ** 31 - 2, 2 ** 31 - 1])
+def test_64_bit_ids_at_the_edge_of_32_bits(top):
+    """Batches of 64-bit ids whose values just fit (a narrowed twin exists: largest id 2^31 - 2) or just do not
+    (2^31 - 1: the pair stays with the 64-bit kernels), smallest id -2^31: same results either way."""
+    rng = np.random.default_rng(top % 1000)
+    pool = np.array([-2 ** 31, -2 ** 31 + 1, -7, 0, 3, 2 ** 20, 2 ** 31 - 3, top], dtype=np.int64)
+
+    def rows(n):
+        off, ids = [0], []
+        for _ in range(n):
+            pick = np.sort(rng.choice(pool, rng.integers(0, len(pool) + 1), replace=False))
+            ids.extend(pick.tolist())
+            off.append(len(ids))
+        return np.array(off, np.uint64), np.array(ids, np.int64)
+
+    t_off, t_ids = rows(21)
+    a_off, a_ids = rows(130)
+    # one row on each side that surely holds both extremes
+    t_off, t_ids = np.append(t_off, t_off[-1] + 2), np.append(t_ids, [-2 ** 31, top])
+    a_off, a_ids = np.append(a_off, a_off[-1] + 3), np.append(a_ids, [-2 ** 31, 3, top])
+    t64, a64 = SDRBatch.from_csr(t_off, t_ids, None), SDRBatch.from_csr(a_off, a_ids, None)
+    assert t64.id_bits == 64
+    t, a = Batch(t_off, t_ids.astype(np.int32), None), Batch(a_off, a_ids.astype(np.int32), None)
+    for op in range(4):
+        got = getattr(t64, OPS[op][0])(a64).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, oracle.port().size_op(op, t, a)), OPS[op][0]
+        off, ids, data = getattr(t64, OPS[op][1])(a64).to_host()
+        w_off, w_ids, _ = oracle.port().elem_op(op, t, a)
+        assert ids.dtype == np.int64 and data is None
+        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids.astype(np.int64)), OPS[op][1]
