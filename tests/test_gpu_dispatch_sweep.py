@@ -132,3 +132,22 @@ def test_64_bit_ids_at_the_edge_of_32_bits(top):
         w_off, w_ids, _ = oracle.port().elem_op(op, t, a)
         assert ids.dtype == np.int64 and data is None
         assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids.astype(np.int64)), OPS[op][1]
+
+
+@pytest.mark.parametrize("len_rows,width", [(64, 4096), (65, 4096), (40, 2048), (40, 4097), (64, 8192)])
+def test_allpairs_default_choice_thresholds(len_rows, width):
+    """All-pairs top-k through the default choice on either side of the bit-sliced kernel's limits (rows of 64 ids,
+    width 4096): overlaps and rows equal the oracle's ranking; k = 16 is the longest list, k = 17 is refused."""
+    import sdr_amd
+    from test_gpu_allpairs import expected_topk
+    rng = np.random.default_rng(len_rows + width)
+    a_csr = util.ragged_rows(rng, 150, width, len_rows, False)
+    b_csr = util.ragged_rows(rng, 1100, width, len_rows, False)
+    a, b = SDRBatch.from_csr(*a_csr, width=width), SDRBatch.from_csr(*b_csr, width=width)
+    counts = oracle.port().size_op(AND, Batch(a_csr[0], a_csr[1], None), Batch(b_csr[0], b_csr[1], None))
+    for k in (1, 16):
+        want_c, want_r = expected_topk(counts, k, -1)
+        got_c, got_r = a.allpairs_topk(b, k)
+        assert np.array_equal(got_r.cpu().numpy(), want_r) and np.array_equal(got_c.cpu().numpy(), want_c), k
+    with pytest.raises(sdr_amd.SdrbError):
+        a.allpairs_topk(b, 17)
