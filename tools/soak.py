@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised soak run on the GPU: random shapes, payload kinds, ops and orientations through the default kernel
+choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids and dot products -- every result
+compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed]
+Prints a line per 50 cases and a summary; exits non-zero on the first mismatch (the failing case is printed so that
+it can be replayed from its seed)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402
+import util  # noqa: E402
+from oracle import Batch  # noqa: E402
+from sdr_amd import SDRBatch  # noqa: E402
+
+SIZE = ("ands", "ors", "xors", "rms")
+ELEM = ("ande", "ore", "xore", "rme")
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t_end = time.time() + budget
+    case = 0
+    checks = 0
+    while time.time() < t_end:
+        seed = seed0 * 1000003 + case
+        rng = np.random.default_rng(seed)
+        width = int(rng.choice([8, 33, 64, 100, 256, 300, 1000, 2048, 2049, 4096, 4097, 9000, 17000, 20000, 30000]))
+        declared = width if rng.random() < 0.8 else 0
+        na = int(rng.choice([1, 2, 3, 8, 9, 16, 17, 31, 32, 33, 64, 65, 100]))
+        nb = int(rng.choice([1, 63, 64, 65, 255, 256, 257, 300, 511, 700]))
+        len_a = int(min(width, rng.choice([0, 1, 5, 20, 40, 41, 64, 65, 128, 129, 300])))
+        len_b = int(min(width, rng.choice([0, 1, 5, 20, 40, 41, 64, 65, 128, 300])))
+        tu, au = bool(rng.integers(2)), bool(rng.integers(2))
+        t = Batch(*util.ragged_rows(rng, na, width, len_a, tu)) if len_a else Batch(
+            np.zeros(na + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if tu else None)
+        a = Batch(*util.ragged_rows(rng, nb, width, len_b, au)) if len_b else Batch(
+            np.zeros(nb + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if au else None)
+        dt = SDRBatch.from_csr(t.off, t.ids, t.data, width=declared)
+        da = SDRBatch.from_csr(a.off, a.ids, a.data, width=declared)
+        tag = dict(seed=seed, width=width, declared=declared, na=na, nb=nb, len_a=len_a, len_b=len_b, tu=tu, au=au)
+        for op in range(4):
+            got = getattr(dt, SIZE[op])(da).cpu().numpy().view(np.uint32)
+            if not np.array_equal(got, oracle.port().size_op(op, t, a)):
+                print("MISMATCH", SIZE[op], tag, flush=True)
+                return 1
+            got = getattr(dt, SIZE[op])(da, swap=True).cpu().numpy().view(np.uint32)
+            if not np.array_equal(got, oracle.port().size_op(op, a, t).T):
+                print("MISMATCH", SIZE[op], "swap", tag, flush=True)
+                return 1
+            off, ids, data = getattr(dt, ELEM[op])(da).to_host()
+            w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+            ok = np.array_equal(off, w_off) and np.array_equal(ids, w_ids) and (
+                (data is None and w_data is None) or
+                (data is not None and w_data is not None and np.array_equal(data.view(np.uint32), w_data.view(np.uint32))))
+            if not ok:
+                print("MISMATCH", ELEM[op], tag, flush=True)
+                return 1
+            checks += 3
+        # now and then: the visitors' records, operator==, the same batches as 64-bit ids, dot products
+        extra = case % 4
+        if extra == 0:
+            for which, name in ((0, "andv"), (1, "orv")):
+                v = getattr(dt, name)(da)
+                off, tp, ap = v.to_host()
+                w_off, w_tp, w_ap = oracle.port().visit(which, t, a)
+                if not (np.array_equal(off, w_off) and np.array_equal(tp, w_tp) and np.array_equal(ap, w_ap)):
+                    print("MISMATCH", name, tag, flush=True)
+                    return 1
+            # (an EmptyData `this` compares with EmptyData rows only, as in the reference)
+            if (tu or not au) and not np.array_equal(dt.equals(da).cpu().numpy().view(np.uint32), oracle.port().equal(t, a)):
+                print("MISMATCH equals", tag, flush=True)
+                return 1
+            checks += 3
+        elif extra == 1:
+            t64 = SDRBatch.from_csr(t.off, t.ids.astype(np.int64) * 3 - 5, t.data)
+            a64 = SDRBatch.from_csr(a.off, a.ids.astype(np.int64) * 3 - 5, a.data)
+            op = case // 4 % 4
+            got = getattr(t64, SIZE[op])(a64).cpu().numpy().view(np.uint32)
+            off, ids, data = getattr(t64, ELEM[op])(a64).to_host()
+            w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+            ok = np.array_equal(got, oracle.port().size_op(op, t, a)) and np.array_equal(off, w_off) and \
+                np.array_equal(ids, w_ids.astype(np.int64) * 3 - 5) and \
+                ((data is None and w_data is None) or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))
+            if not ok:
+                print("MISMATCH 64-bit ids", SIZE[op], tag, flush=True)
+                return 1
+            checks += 2
+        elif extra == 2 and len_a and len_b:
+            ta = util.arith_rows(rng, na, width, len_a)
+            aa = util.arith_rows(rng, nb, width, len_b)
+            dta = SDRBatch.from_csr(*ta, width=declared, kind="arith")
+            daa = SDRBatch.from_csr(*aa, width=declared, kind="arith")
+            want = oracle.port().inner(Batch(*ta), Batch(*aa)).view(np.uint32)
+            if not np.array_equal(dta.inner(daa).cpu().numpy().view(np.uint32), want):
+                print("MISMATCH inner", tag, flush=True)
+                return 1
+            checks += 1
+        case += 1
+        if case % 50 == 0:
+            print(f"{case} cases, {checks} comparisons, all equal", flush=True)
+    print(f"soak done: {case} cases, {checks} comparisons, all equal", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
