@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak run on the GPU: random shapes, payload kinds, ops and orientations through the default kernel
 choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids and dot products -- every result
-compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed]
+compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big]
 Prints a line per 50 cases and a summary; exits non-zero on the first mismatch (the failing case is printed so that
 it can be replayed from its seed)."""
 import os
@@ -25,6 +25,7 @@ ELEM = ("ande", "ore", "xore", "rme")
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     t_end = time.time() + budget
     case = 0
     checks = 0
@@ -35,6 +36,11 @@ def main():
         declared = width if rng.random() < 0.8 else 0
         na = int(rng.choice([1, 2, 3, 8, 9, 16, 17, 31, 32, 33, 64, 65, 100]))
         nb = int(rng.choice([1, 63, 64, 65, 255, 256, 257, 300, 511, 700]))
+        if big:   # several tiles of A, many blocks of B, the benchmark's row shapes
+            width = int(rng.choice([256, 2048, 4096, 16384]))
+            declared = width
+            na = int(rng.choice([33, 64, 65, 130]))
+            nb = int(rng.choice([1025, 2500, 4000]))
         len_a = int(min(width, rng.choice([0, 1, 5, 20, 40, 41, 64, 65, 128, 129, 300])))
         len_b = int(min(width, rng.choice([0, 1, 5, 20, 40, 41, 64, 65, 128, 300])))
         tu, au = bool(rng.integers(2)), bool(rng.integers(2))
@@ -103,7 +109,7 @@ def main():
                 return 1
             checks += 1
         case += 1
-        if case % 50 == 0:
+        if case % (5 if big else 50) == 0:
             print(f"{case} cases, {checks} comparisons, all equal", flush=True)
     print(f"soak done: {case} cases, {checks} comparisons, all equal", flush=True)
     return 0
