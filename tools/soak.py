@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak run on the GPU: random shapes, payload kinds, ops and orientations through the default kernel
-choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids and dot products -- every result
+choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids, dot products, the row-wise forms,
+range and point queries -- every result
 compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big]
 Prints a line per 50 cases and a summary; exits non-zero on the first mismatch (the failing case is printed so that
 it can be replayed from its seed)."""
@@ -108,6 +109,42 @@ def main():
                 print("MISMATCH inner", tag, flush=True)
                 return 1
             checks += 1
+        elif extra == 3:
+            # row by row (the in-place forms): the diagonal of the all-pairs results; range and point queries
+            n = min(na, nb)
+            if n:
+                ts = Batch(t.off[: n + 1], t.ids[: int(t.off[n])], None if t.data is None else t.data[: int(t.off[n])])
+                as_ = Batch(a.off[: n + 1], a.ids[: int(a.off[n])], None if a.data is None else a.data[: int(a.off[n])])
+                dts = SDRBatch.from_csr(ts.off, ts.ids, ts.data, width=declared)
+                das = SDRBatch.from_csr(as_.off, as_.ids, as_.data, width=declared)
+                op = case // 4 % 4
+                want = np.diagonal(oracle.port().size_op(op, ts, as_))
+                if not np.array_equal(dts.rowwise_size(SIZE[op], das).cpu().numpy().view(np.uint32), want):
+                    print("MISMATCH row-wise", SIZE[op], tag, flush=True)
+                    return 1
+                off, ids, data = dts.rowwise_elem(ELEM[op], das).to_host()
+                w_off, w_ids, w_data = oracle.port().elem_op(op, ts, as_)
+                for r in range(n):
+                    p = r * n + r
+                    lo, hi = int(w_off[p]), int(w_off[p + 1])
+                    same = np.array_equal(ids[int(off[r]):int(off[r + 1])], w_ids[lo:hi]) and (
+                        w_data is None or np.array_equal(data[int(off[r]):int(off[r + 1])].view(np.uint32), w_data[lo:hi].view(np.uint32)))
+                    if not same:
+                        print("MISMATCH row-wise", ELEM[op], "row", r, tag, flush=True)
+                        return 1
+                checks += 2
+            if nb and len_b:
+                lo = rng.integers(-5, width, 7).astype(np.int32)
+                hi = (lo + rng.integers(0, width, 7)).astype(np.int32)
+                counts, _ = oracle.port().range_size(a, lo, hi)
+                if not np.array_equal(da.range_size(lo, hi).cpu().numpy().view(np.uint32), counts):
+                    print("MISMATCH range_size", tag, flush=True)
+                    return 1
+                qid = rng.integers(-2, width + 2, 9).astype(np.int32)
+                if not np.array_equal(da.point_query(qid).cpu().numpy(), oracle.port().point(a, qid)):
+                    print("MISMATCH point_query", tag, flush=True)
+                    return 1
+                checks += 2
         case += 1
         if case % (5 if big else 50) == 0:
             print(f"{case} cases, {checks} comparisons, all equal", flush=True)
