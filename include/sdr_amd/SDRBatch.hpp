@@ -220,6 +220,31 @@ class Visits {
     struct Host {
         std::vector<uint32_t> offsets, this_pos, arg_pos;
     };
+    // The reference's five-callback orv (SDR.hpp:284-285, 1099-1150) stops calling the single-side visitors once one
+    // side is exhausted and hands the rest of the other side over in ONE call: arg_only_position(arg position) when
+    // `this` runs out (it is asked first, so also when both end together), else this_only_position(this position).
+    // For pair `p` of an orv result, given the lengths of the two rows: the records [offsets[p], head_end) are the
+    // visitor calls made before that, then comes the one position call.
+    struct OrvTail {
+        uint32_t head_end;      // index into this_pos / arg_pos: the records from here on are the handed-over tail
+        bool arg_only;          // true: arg_only_position(position), false: this_only_position(position)
+        uint32_t position;      // where the tail starts in its row (may be the row's end)
+    };
+    static OrvTail orv_tail(const Host& h, size_t p, uint32_t this_len, uint32_t arg_len) {
+        uint32_t k = h.offsets[p], seen_this = 0, seen_arg = 0;
+        const uint32_t end = h.offsets[p + 1];
+        // the merge asks `this` first, then `arg`; after a call it asks the side(s) it has just advanced
+        if (this_len == 0) return {k, true, 0};
+        if (arg_len == 0) return {k, false, 0};
+        for (; k < end; ++k) {
+            const bool has_this = h.this_pos[k] != SDRB_POS_NONE, has_arg = h.arg_pos[k] != SDRB_POS_NONE;
+            seen_this += has_this;
+            seen_arg += has_arg;
+            if (has_this && seen_this == this_len) return {k + 1, true, seen_arg};
+            if (has_arg && seen_arg == arg_len) return {k + 1, false, seen_this};
+        }
+        return {end, true, seen_arg};   // not reached for rows of the stated lengths
+    }
     Host to_host(void* stream = nullptr) const {
         Host h;
         h.offsets = offsets.to_host<uint32_t>(na * nb + 1, stream);

@@ -170,6 +170,42 @@ class VisitResult:
         return VisitResult(self.na, self.nb, off32, self.this_pos[keep], self.arg_pos[keep], int(kept_upto[-1]))
 
 
+    def orv_tails(self, this_lens, arg_lens):
+        """The reference's five-callback ``orv`` (SDR.hpp:284-285, 1099-1150) for every pair of an ``orv`` result: it
+        calls the single-side visitors only until one side is exhausted and then hands the rest of the other side over
+        in ONE call -- ``arg_only_position(arg position)`` when ``this`` runs out (``this`` is asked first, so also
+        when both end together), else ``this_only_position(this position)``.  ``this_lens`` [na] and ``arg_lens`` [nb]
+        are the row lengths.  Returns host arrays over the pairs: ``head_end`` (records ``offsets[p] : head_end[p]`` are
+        the visitor calls made before the position call), ``arg_only`` (bool: which position call) and ``position``
+        (where the handed-over tail starts in its row; may be the row's end)."""
+        off, tp, ap = self.to_host()
+        this_len = np.repeat(np.asarray(this_lens, dtype=np.int64), self.nb)
+        arg_len = np.tile(np.asarray(arg_lens, dtype=np.int64), self.na)
+        n_pairs = self.na * self.nb
+        counts = np.diff(off).astype(np.int64)
+        pid = np.repeat(np.arange(n_pairs), counts)
+        has_t, has_a = tp != POS_NONE, ap != POS_NONE
+        cum_t = np.concatenate([[0], np.cumsum(has_t)])
+        cum_a = np.concatenate([[0], np.cumsum(has_a)])
+        start = off[:-1].astype(np.int64)
+        seen_t = cum_t[1:] - cum_t[start][pid]
+        seen_a = cum_a[1:] - cum_a[start][pid]
+        end_t = has_t & (seen_t == this_len[pid])
+        end_a = has_a & (seen_a == arg_len[pid]) & ~end_t
+        k = np.arange(tp.size, dtype=np.int64)
+        first = np.full(n_pairs, np.iinfo(np.int64).max)
+        np.minimum.at(first, pid, np.where(end_t | end_a, k, np.iinfo(np.int64).max))
+        head_end = start.copy()
+        arg_only = this_len == 0
+        position = np.zeros(n_pairs, dtype=np.int64)
+        live = (this_len > 0) & (arg_len > 0)
+        f = first[live]
+        head_end[live] = f + 1
+        arg_only[live] = end_t[f]
+        position[live] = np.where(end_t[f], seen_a[f], seen_t[f])
+        return head_end, arg_only, position
+
+
 POS_NONE = 0xFFFFFFFF
 
 

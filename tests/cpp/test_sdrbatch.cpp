@@ -407,7 +407,44 @@ int run_visitors(std::mt19937& rng, const char* name) {
                           rec((uint32_t)(tp - qs[i].begin()), (uint32_t)(ap - ds[j].begin()));
                       });
             REQUIRE(ok && k == ov.offsets[p + 1]);
+            // the five-callback form (SDR.hpp:284-285): visitor calls up to the point where one side is exhausted, then
+            // ONE position call for the rest of the other side
+            k = ov.offsets[p];
+            int tail_calls = 0;
+            bool tail_arg_only = false;
+            uint32_t tail_pos = 0;
+            qs[i].orv(ds[j],
+                      [&](SDR<U>::iterator tp) { rec((uint32_t)(tp - qs[i].begin()), SDRB_POS_NONE); },
+                      [&](SDR<E>::iterator ap) { rec(SDRB_POS_NONE, (uint32_t)(ap - ds[j].begin())); },
+                      [&](SDR<U>::iterator tp, SDR<E>::iterator ap) {
+                          rec((uint32_t)(tp - qs[i].begin()), (uint32_t)(ap - ds[j].begin()));
+                      },
+                      [&](SDR<U>::iterator tp) { ++tail_calls; tail_arg_only = false; tail_pos = (uint32_t)(tp - qs[i].begin()); },
+                      [&](SDR<E>::iterator ap) { ++tail_calls; tail_arg_only = true; tail_pos = (uint32_t)(ap - ds[j].begin()); });
+            const auto tail = sdr_amd::Visits::orv_tail(ov, p, (uint32_t)qs[i].size(), (uint32_t)ds[j].size());
+            REQUIRE(ok && tail_calls == 1 && k == tail.head_end && tail.arg_only == tail_arg_only && tail.position == tail_pos);
         }
+    // rows that end together, an empty `this`, an empty `arg`
+    {
+        std::vector<SDR<U>> ts(3);
+        std::vector<SDR<E>> as(3);
+        for (int id : {2, 5, 9}) { ts[0].push_back(U(id, UnitData(0.5f))); as[0].push_back(E(id)); }
+        for (int id : {1, 4}) as[1].push_back(E(id));          // ts[1] empty
+        for (int id : {3, 8}) ts[2].push_back(U(id, UnitData(0.5f)));   // as[2] empty
+        auto tb = sdr_amd::SDRBatch::pack(ts.begin(), ts.end(), 0, 16), ab = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 16);
+        auto h = tb.orv(ab, SDRB_FLAG_ROWWISE).to_host();
+        for (size_t r = 0; r < 3; ++r) {
+            int tail_calls = 0;
+            bool tail_arg_only = false;
+            uint32_t tail_pos = 0, visits = 0;
+            ts[r].orv(as[r], [&](SDR<U>::iterator) { ++visits; }, [&](SDR<E>::iterator) { ++visits; },
+                      [&](SDR<U>::iterator, SDR<E>::iterator) { ++visits; },
+                      [&](SDR<U>::iterator tp) { ++tail_calls; tail_arg_only = false; tail_pos = (uint32_t)(tp - ts[r].begin()); },
+                      [&](SDR<E>::iterator ap) { ++tail_calls; tail_arg_only = true; tail_pos = (uint32_t)(ap - as[r].begin()); });
+            const auto tail = sdr_amd::Visits::orv_tail(h, r, (uint32_t)ts[r].size(), (uint32_t)as[r].size());
+            REQUIRE(tail_calls == 1 && tail.head_end - h.offsets[r] == visits && tail.arg_only == tail_arg_only && tail.position == tail_pos);
+        }
+    }
     // operator== for every pair (a few rows are made equal on purpose)
     for (size_t r : {size_t(1), size_t(2)}) {
         SDR<E> same;

@@ -176,3 +176,47 @@ def test_andv_over_sub_ranges():
     w_off, w_tp, w_ap = want.to_host()
     assert got.total == want.total and np.array_equal(g_off, w_off)
     assert np.array_equal(g_tp, w_tp + t_lo) and np.array_equal(g_ap, w_ap + a_lo)
+
+
+@pytest.mark.gpu
+def test_orv_five_callback_tails():
+    """The five-callback orv (SDR.hpp:284-285, 1099-1150), restated here call by call: single-side visitors until one side
+    is exhausted, then one position call for the rest of the other side.  VisitResult.orv_tails must name, for every
+    pair, the same number of visitor calls, the same position call and the same position -- rows that end together,
+    empty rows on either side and ordinary ragged rows."""
+    import util
+    from oracle import Batch
+    from sdr_amd import SDRBatch
+    rng = np.random.default_rng(5)
+    t = Batch(*util.ragged_rows(rng, 23, 60, 30, False))
+    a = Batch(*util.ragged_rows(rng, 41, 60, 30, False))
+    # make some rows empty and some pairs identical
+    t_rows = [t.row(r)[0].tolist() for r in range(t.n)]
+    a_rows = [a.row(r)[0].tolist() for r in range(a.n)]
+    t_rows[3], a_rows[5], a_rows[6] = [], [], list(t_rows[0])
+    t, a = Batch.from_rows(t_rows), Batch.from_rows(a_rows)
+    res = SDRBatch.from_csr(t.off, t.ids, None, width=60).orv(SDRBatch.from_csr(a.off, a.ids, None, width=60))
+    off, _, _ = res.to_host()
+    head_end, arg_only, position = res.orv_tails(np.diff(t.off), np.diff(a.off))
+
+    def five_callbacks(x, y):
+        i = j = calls = 0
+        while True:
+            if i == len(x):
+                return calls, True, j          # arg_only_position(arg_pos)
+            if j == len(y):
+                return calls, False, i         # this_only_position(this_pos)
+            if x[i] < y[j]:
+                i += 1
+            elif x[i] > y[j]:
+                j += 1
+            else:
+                i += 1
+                j += 1
+            calls += 1
+
+    for i in range(t.n):
+        for j in range(a.n):
+            p = i * a.n + j
+            calls, which, pos = five_callbacks(t_rows[i], a_rows[j])
+            assert head_end[p] - off[p] == calls and bool(arg_only[p]) == which and position[p] == pos, (i, j)
