@@ -2,7 +2,7 @@
 """Randomised soak run on the GPU: random shapes, payload kinds, ops and orientations through the default kernel
 choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids, dot products, the row-wise forms,
 range and point queries -- every result
-compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big]
+compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big|algos]
 Prints a line per 50 cases and a summary; exits non-zero on the first mismatch (the failing case is printed so that
 it can be replayed from its seed)."""
 import os
@@ -27,6 +27,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    algos = len(sys.argv) > 3 and sys.argv[3] == "algos"
     t_end = time.time() + budget
     case = 0
     checks = 0
@@ -70,6 +71,38 @@ def main():
                 print("MISMATCH", ELEM[op], tag, flush=True)
                 return 1
             checks += 3
+        if algos:
+            # every kernel that accepts the shapes, not only the one the library would choose
+            from sdr_amd import SdrbError
+            for op in range(4):
+                want_s, want_sw = oracle.port().size_op(op, t, a), oracle.port().size_op(op, a, t).T
+                for algo in ("merge", "bitslice", "popcount", "rowtable", "masktable", "lanerows"):
+                    for swap, want in ((False, want_s), (True, want_sw)):
+                        try:
+                            got = getattr(dt, SIZE[op])(da, swap=swap, algo=algo).cpu().numpy().view(np.uint32)
+                        except SdrbError as e:
+                            if e.code != -5:
+                                raise
+                            continue
+                        if not np.array_equal(got, want):
+                            print("MISMATCH", SIZE[op], "algo", algo, "swap", swap, tag, flush=True)
+                            return 1
+                        checks += 1
+                w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+                for algo in ("merge", "rank", "bitmap", "lanemerge", "lanerank", "masktable"):
+                    try:
+                        off, ids, data = getattr(dt, ELEM[op])(da, algo=algo).to_host()
+                    except SdrbError as e:
+                        if e.code != -5:
+                            raise
+                        continue
+                    ok = np.array_equal(off, w_off) and np.array_equal(ids, w_ids) and (
+                        (data is None and w_data is None) or
+                        (data is not None and w_data is not None and np.array_equal(data.view(np.uint32), w_data.view(np.uint32))))
+                    if not ok:
+                        print("MISMATCH", ELEM[op], "algo", algo, tag, flush=True)
+                        return 1
+                    checks += 1
         # now and then: the visitors' records, operator==, the same batches as 64-bit ids, dot products
         extra = case % 4
         if extra == 0:
