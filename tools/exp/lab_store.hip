@@ -72,6 +72,36 @@ __global__ void k_tiles_quad8(uint32_t* out, size_t ld) {
     }
 }
 
+
+// (c3) the dword tiles with the block index remapped so that each XCD (blocks are dealt to the eight XCDs
+// round robin) owns runs of C consecutive 1-KiB column segments; C = 0: one contiguous eighth of the columns
+template <int NT>
+__global__ void k_tiles_xcd(uint32_t* out, size_t ld, int C) {
+    const uint32_t bid = blockIdx.x, nblk = gridDim.x, xcd = bid & 7, idx = bid >> 3;
+    const uint32_t jb = C == 0 ? xcd * (nblk / 8) + idx : (idx / C) * 8 * C + xcd * C + idx % C;
+    size_t j = (size_t)jb * blockDim.x + threadIdx.x;
+    for (int t = 0; t < Q / 64; ++t) {
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            uint32_t* p = out + (size_t)(t * 64 + q) * ld + j;
+            if (NT) __builtin_nontemporal_store((uint32_t)(q + t), p); else *p = q + t;
+        }
+    }
+}
+// (c4) tiles walked by a block that covers S consecutive 1-KiB segments per row (S stores of one row back to back)
+template <int S>
+__global__ void k_tiles_wide(uint32_t* out, size_t ld) {
+    size_t j = (size_t)blockIdx.x * blockDim.x * S + threadIdx.x;
+    for (int t = 0; t < Q / 64; ++t) {
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q) {
+            uint32_t* p = out + (size_t)(t * 64 + q) * ld + j;
+#pragma unroll
+            for (int s = 0; s < S; ++s) p[s * 256] = q + t + s;
+        }
+    }
+}
+
 // (d) each block owns one contiguous chunk and sweeps it front to back
 template <int W>
 __global__ void k_chunked(uint32_t* out, size_t chunk_elems) {
@@ -102,6 +132,28 @@ float timeit(F f, int reps = 5) {
 int main(int argc, char** argv) {
     uint32_t* out; size_t bytes = (size_t)Q * N * 4;
     CK(hipMalloc(&out, bytes));
+    if (argc > 1 && argv[1][0] == 'x') {   // block-to-column mappings and store hints for the dword tiles
+        auto rep = [&](const char* name, float ms) { printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+        rep("hipMemsetAsync", timeit([&] { CK(hipMemsetAsync(out, 1, bytes, 0)); }));
+        rep("tiles RPL1 block=256", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }));
+        for (int C : {0, 1, 2, 4, 16, 64}) {
+            char nm[64]; snprintf(nm, 64, "tiles xcd-remap C=%d", C);
+            rep(nm, timeit([&] { k_tiles_xcd<0><<<N / 256, 256>>>(out, N, C); }));
+        }
+        rep("tiles NT", timeit([&] { k_tiles_xcd<1><<<N / 256, 256>>>(out, N, 1); }));
+        rep("tiles NT xcd-remap C=0", timeit([&] { k_tiles_xcd<1><<<N / 256, 256>>>(out, N, 0); }));
+        rep("tiles NT xcd-remap C=4", timeit([&] { k_tiles_xcd<1><<<N / 256, 256>>>(out, N, 4); }));
+        rep("tiles wide S=2", timeit([&] { k_tiles_wide<2><<<N / 512, 256>>>(out, N); }));
+        rep("tiles wide S=4", timeit([&] { k_tiles_wide<4><<<N / 1024, 256>>>(out, N); }));
+        rep("tiles wide S=8", timeit([&] { k_tiles_wide<8><<<N / 2048, 256>>>(out, N); }));
+        rep("tiles RPL1 block=512", timeit([&] { k_tiles<1><<<N / 512, 512>>>(out, N); }));
+        rep("tiles RPL1 block=1024", timeit([&] { k_tiles<1><<<N / 1024, 1024>>>(out, N); }));
+        for (int g : {1024, 4096, 16384}) { char nm[64]; size_t chunk = (size_t)Q * N / g;
+            snprintf(nm, 64, "chunked x4 grid=%d block=256", g); rep(nm, timeit([&] { k_chunked<4><<<g, 256>>>(out, chunk); })); }
+        rep("linear16 grid=8192", timeit([&] { k_linear16<<<8192, 256>>>((uint4*)out, bytes / 16); }));
+        rep("tiles RPL1 block=256", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }));
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'q') {   // only the quad-exchange shapes against the dword tiles
         auto rep = [&](const char* name, float ms) { printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
         rep("hipMemsetAsync", timeit([&] { CK(hipMemsetAsync(out, 1, bytes, 0)); }));
