@@ -613,6 +613,87 @@ __global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__
     }
 }
 
+// The same ordering with a block's pairs staged in LDS and a thread per ELEMENT: 256 consecutive pairs hold one
+// contiguous piece of the result, which the block fetches with coalesced loads as (id, payload) words.  An element's
+// place in its pair is the number of the pair's elements with a smaller id (ids of a pair are distinct), counted with
+// independent LDS reads -- no lane waits for the longest pair of its wave to finish a serial insertion sort -- and
+// only elements that move are written back.  A block whose piece exceeds the stage sorts in place in memory.
+// `stage`: elements a block can stage (dynamic LDS: stage * (sizeof(kv_t) + 1) + 257 * 4 bytes; a multiple of 4)
+template <bool DATA>
+__global__ __launch_bounds__(256) void k_sort_pairs_staged(const uint32_t* __restrict__ off, uint64_t n_pairs,
+                                                           int32_t* __restrict__ ids, float* __restrict__ data,
+                                                           uint32_t stage) {
+    using kv_t = std::conditional_t<DATA, unsigned long long, uint32_t>;   // id (sign bit flipped) above the payload
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    kv_t* kv = reinterpret_cast<kv_t*>(sort_lds);                            // [stage]
+    uint32_t* edge = reinterpret_cast<uint32_t*>(kv + stage);                // [257] the pairs' offsets relative to the block's first element
+    unsigned char* owner = reinterpret_cast<unsigned char*>(edge + 257);     // [stage] which of the block's pairs an element belongs to
+    const uint32_t tid = threadIdx.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * 256;
+    const uint64_t p1 = p0 + 256 < n_pairs ? p0 + 256 : n_pairs;
+    const uint32_t blk_lo = off[p0], span = off[p1] - blk_lo;   // uniform
+    uint32_t lo = 0, hi = 0;
+    if (p0 + tid < n_pairs) {
+        lo = off[p0 + tid];
+        hi = off[p0 + tid + 1];
+    }
+    if (span > stage) {
+        for (uint32_t k = lo + 1; k < hi; ++k) {
+            const int32_t id = ids[k];
+            const float d = DATA ? data[k] : 0.0f;
+            uint32_t s = k;
+            while (s > lo && ids[s - 1] > id) {
+                ids[s] = ids[s - 1];
+                if constexpr (DATA) data[s] = data[s - 1];
+                --s;
+            }
+            if (s != k) {
+                ids[s] = id;
+                if constexpr (DATA) data[s] = d;
+            }
+        }
+        return;
+    }
+    if (!__syncthreads_or(hi - lo >= 2u)) return;
+    // eight loads in flight a thread: with one, a block's few thousand bytes arrive at the latency of memory
+    for (uint32_t base = 0; base < span; base += 8 * 256) {
+        uint32_t key[8], val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t e = base + u * 256 + tid;
+            key[u] = e < span ? (uint32_t)ids[blk_lo + e] : 0u;
+            val[u] = (DATA && e < span) ? __float_as_uint(data[blk_lo + e]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t e = base + u * 256 + tid;
+            if (e < span) {
+                if constexpr (DATA) kv[e] = ((unsigned long long)(key[u] ^ 0x80000000u) << 32) | val[u];
+                else kv[e] = key[u] ^ 0x80000000u;
+            }
+        }
+    }
+    edge[tid] = (p0 + tid < n_pairs ? lo : off[p1]) - blk_lo;
+    if (tid == 0) edge[256] = span;
+    for (uint32_t e = lo - blk_lo; e < hi - blk_lo; ++e) owner[e] = (unsigned char)tid;
+    __syncthreads();
+    for (uint32_t e = tid; e < span; e += 256) {
+        const uint32_t p = owner[e];
+        const uint32_t l0 = edge[p], l1 = edge[p + 1];
+        const kv_t x = kv[e];
+        uint32_t at = l0;
+        for (uint32_t k = l0; k < l1; ++k) at += kv[k] < x ? 1u : 0u;
+        if (at != e) {
+            if constexpr (DATA) {
+                ids[blk_lo + at] = (int32_t)((uint32_t)(x >> 32) ^ 0x80000000u);
+                data[blk_lo + at] = __uint_as_float((uint32_t)x);
+            } else {
+                ids[blk_lo + at] = (int32_t)(x ^ 0x80000000u);
+            }
+        }
+    }
+}
+
 size_t lds_bytes(uint32_t width, int tile = 64) {
     const size_t entries = (size_t)(width + 1) + ((width + 1) & 1u);
     return entries * (tile / 8) + (size_t)kGroup * cnt_ld(tile) * 4 + (tile + kGroup) * 4;
@@ -726,7 +807,19 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
         const dim3 sort_grid((uint32_t)((pairs + 256ull * ppt - 1) / (256ull * ppt)));
         int32_t* const sort_ids = out_ids;
         float* const sort_data = math == kKeepAll ? nullptr : out_data;
-        if (math == kKeepAll && ppt == 4)
+        // pairs of several elements: staged in LDS (one coalesced pass); sparse results: four pairs a thread in place
+        const dim3 staged_grid((uint32_t)((pairs + 255) / 256));
+        // room for the expected id matches of 256 pairs and a sixth more (payload rules only drop matches; a block
+        // that holds more still sorts, in place), 2048 or 4096 elements: a smaller stage lets more blocks share a
+        // compute unit
+        const uint32_t stage = expected * 300.0 <= 2048.0 ? 2048u : 4096u;
+        const size_t kv_bytes = math == kKeepAll ? 4 : 8;
+        const size_t sort_lds = (size_t)stage * (kv_bytes + 1) + 257 * 4;
+        if (ppt == 1 && math == kKeepAll)
+            hipLaunchKernelGGL((k_sort_pairs_staged<false>), staged_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
+        else if (ppt == 1)
+            hipLaunchKernelGGL((k_sort_pairs_staged<true>), staged_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
+        else if (math == kKeepAll && ppt == 4)
             hipLaunchKernelGGL((k_sort_pairs<false, 4>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
         else if (math == kKeepAll)
             hipLaunchKernelGGL((k_sort_pairs<false, 1>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);

@@ -482,12 +482,14 @@ def test_rowwise_needs_equal_lengths():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(PAIRINGS))
-@pytest.mark.parametrize("width,max_len", [(16384, 328), (2048, 40), (9000, 200), (40000, 90)])
+@pytest.mark.parametrize("width,max_len", [(16384, 328), (2048, 40), (9000, 200), (40000, 90), (700, 200), (500, 200)])
 def test_mask_table_kernel_many_tiles_and_groups(name, width, max_len):
     """The mask-table kernel over several tiles of A (partial last tile), several 64-row groups of B
     (partial last group) and rows of several 64-element chunks; the shapes pick its variants: 32-row
     tiles with the payloads of A in LDS, 64-row tiles with them, and (width 40000: too wide for the
-    table) the fallback."""
+    table) the fallback.  The fill's pair sort: four pairs a thread in place (sparse results: 2048/40,
+    9000/200), 256 pairs staged in LDS (16384/328, 700/200: about 14 elements a pair), and blocks whose 256
+    pairs hold more than the stage (500/200: about 20 elements a pair), which sort in place."""
     tu, au = PAIRINGS[name]
     rng = np.random.default_rng(99 + 2 * tu + au + width)
     t = Batch(*util.ragged_rows(rng, 150, width, max_len, tu))
