@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restric
 
 // FILL == false: size ops (counters -> sizes).  FILL == true: ande -- the counter tile starts at the
 // pairs' output offsets and every kept match takes the next slot of its pair; slots of one pair are
-// claimed by concurrent lanes, so a pair's elements are put in id order afterwards (k_sort_pairs).
+// claimed by concurrent lanes, so a pair's elements are put in id order afterwards (k_sort_pairs_staged).
 template <int MATH, int NIT, bool FILL, bool FLAT, int TILE>
 __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val_dense,
@@ -500,161 +500,59 @@ __global__ __launch_bounds__(kFewBlock) void k_size_few_payload(
     }
 }
 
-// One thread per pair puts the pair's few elements in id order (payloads travel along).  Pairs of two to
-// four elements -- nearly all that need any work -- fetch their elements together and run a sorting
-// network in registers (one round trip to memory instead of one per insertion step); longer pairs use
-// an insertion sort in place.  Ids of a pair are distinct.
-template <int N, bool DATA>
-__device__ __forceinline__ void sort_small(uint32_t lo, int32_t* __restrict__ ids, float* __restrict__ data) {
-    int32_t id[N];
-    float d[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        id[u] = ids[lo + u];
-        d[u] = DATA ? data[lo + u] : 0.0f;
-    }
-    constexpr int kNet[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};   // N = 4; N = 3 uses (0,1),(1,2),(0,1)
-    bool changed = false;
-    auto exchange = [&](int x, int y) {
-        if (id[x] > id[y]) {
-            const int32_t ti = id[x];
-            id[x] = id[y];
-            id[y] = ti;
-            const float td = d[x];
-            d[x] = d[y];
-            d[y] = td;
-            changed = true;
-        }
-    };
-    if constexpr (N == 2) {
-        exchange(0, 1);
-    } else if constexpr (N == 3) {
-        exchange(0, 1);
-        exchange(1, 2);
-        exchange(0, 1);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 5; ++c) exchange(kNet[c][0], kNet[c][1]);
-    }
-    if (changed) {
-#pragma unroll
-        for (int u = 0; u < N; ++u) {
-            ids[lo + u] = id[u];
-            if constexpr (DATA) data[lo + u] = d[u];
-        }
-    }
-}
-
-// kPairsPerThread consecutive pairs per thread (four where most pairs hold fewer than three elements, else
-// one): their offsets arrive together, and the first
-// two elements of every pair that has two or more are requested together, so a thread waits once for
-// memory where a pair at a time would wait once per pair (most pairs hold fewer than three elements).
-template <bool DATA, int kPairsPerThread>
-__global__ __launch_bounds__(256) void k_sort_pairs(const uint32_t* __restrict__ off, uint64_t n_pairs,
-                                                    int32_t* __restrict__ ids, float* __restrict__ data) {
-    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * kPairsPerThread;
-    if (p0 >= n_pairs) return;
-    uint32_t edge[kPairsPerThread + 1];
-#pragma unroll
-    for (int u = 0; u <= kPairsPerThread; ++u) edge[u] = off[p0 + u <= n_pairs ? p0 + u : n_pairs];
-    int32_t first[kPairsPerThread], second[kPairsPerThread];
-    float dfirst[kPairsPerThread], dsecond[kPairsPerThread];
-#pragma unroll
-    for (int u = 0; u < kPairsPerThread; ++u) {
-        const uint32_t lo = edge[u], n = edge[u + 1] - lo;
-        first[u] = second[u] = 0;
-        dfirst[u] = dsecond[u] = 0.0f;
-        if (n >= 2) {
-            first[u] = ids[lo];
-            second[u] = ids[lo + 1];
-            if constexpr (DATA) {
-                dfirst[u] = data[lo];
-                dsecond[u] = data[lo + 1];
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < kPairsPerThread; ++u) {
-        const uint32_t lo = edge[u], hi = edge[u + 1], n = hi - lo;
-        if (n < 2) continue;
-        if (n == 2) {
-            if (first[u] > second[u]) {
-                ids[lo] = second[u];
-                ids[lo + 1] = first[u];
-                if constexpr (DATA) {
-                    data[lo] = dsecond[u];
-                    data[lo + 1] = dfirst[u];
-                }
-            }
-            continue;
-        }
-        if (n == 3) {
-            sort_small<3, DATA>(lo, ids, data);
-            continue;
-        }
-        if (n == 4) {
-            sort_small<4, DATA>(lo, ids, data);
-            continue;
-        }
-        for (uint32_t k = lo + 1; k < hi; ++k) {
-            const int32_t id = ids[k];
-            const float d = DATA ? data[k] : 0.0f;
-            uint32_t s = k;
-            while (s > lo && ids[s - 1] > id) {
-                ids[s] = ids[s - 1];
-                if constexpr (DATA) data[s] = data[s - 1];
-                --s;
-            }
-            if (s != k) {
-                ids[s] = id;
-                if constexpr (DATA) data[s] = d;
-            }
-        }
-    }
-}
-
-// The same ordering with a block's pairs staged in LDS and a thread per ELEMENT: 256 consecutive pairs hold one
-// contiguous piece of the result, which the block fetches with coalesced loads as (id, payload) words.  An element's
-// place in its pair is the number of the pair's elements with a smaller id (ids of a pair are distinct), counted with
-// independent LDS reads -- no lane waits for the longest pair of its wave to finish a serial insertion sort -- and
-// only elements that move are written back.  A block whose piece exceeds the stage sorts in place in memory.
-// `stage`: elements a block can stage (dynamic LDS: stage * (sizeof(kv_t) + 1) + 257 * 4 bytes; a multiple of 4)
-template <bool DATA>
+// Puts every pair's few elements in id order (payloads travel along), a block's pairs staged in LDS and a thread
+// per ELEMENT: 256 * PPT consecutive pairs hold one contiguous piece of the result, which the block fetches with coalesced loads as (id, payload) words.  An
+// element's place in its pair is the number of the pair's elements with a smaller id (ids of a pair are distinct),
+// counted with independent LDS reads -- no lane waits for the longest pair of its wave to finish a serial insertion
+// sort -- and only elements that move are written back.  A block whose piece exceeds the stage sorts in place in
+// memory.  `stage`: elements a block can stage, a multiple of 4 (dynamic LDS: sort_stage_lds()).
+template <bool DATA, int PPT>
 __global__ __launch_bounds__(256) void k_sort_pairs_staged(const uint32_t* __restrict__ off, uint64_t n_pairs,
                                                            int32_t* __restrict__ ids, float* __restrict__ data,
                                                            uint32_t stage) {
     using kv_t = std::conditional_t<DATA, unsigned long long, uint32_t>;   // id (sign bit flipped) above the payload
+    using own_t = std::conditional_t<PPT == 1, unsigned char, uint16_t>;
+    constexpr uint32_t PPB = 256 * PPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
-    kv_t* kv = reinterpret_cast<kv_t*>(sort_lds);                            // [stage]
-    uint32_t* edge = reinterpret_cast<uint32_t*>(kv + stage);                // [257] the pairs' offsets relative to the block's first element
-    unsigned char* owner = reinterpret_cast<unsigned char*>(edge + 257);     // [stage] which of the block's pairs an element belongs to
+    kv_t* kv = reinterpret_cast<kv_t*>(sort_lds);                    // [stage]
+    uint32_t* edge = reinterpret_cast<uint32_t*>(kv + stage);        // [PPB + 1] pairs' offsets relative to the block's first element
+    own_t* owner = reinterpret_cast<own_t*>(edge + PPB + 1);         // [stage] which of the block's pairs an element belongs to
     const uint32_t tid = threadIdx.x;
-    const uint64_t p0 = (uint64_t)blockIdx.x * 256;
-    const uint64_t p1 = p0 + 256 < n_pairs ? p0 + 256 : n_pairs;
-    const uint32_t blk_lo = off[p0], span = off[p1] - blk_lo;   // uniform
-    uint32_t lo = 0, hi = 0;
-    if (p0 + tid < n_pairs) {
-        lo = off[p0 + tid];
-        hi = off[p0 + tid + 1];
+    const uint64_t p0 = (uint64_t)blockIdx.x * PPB;
+    const uint32_t np = (uint32_t)(p0 + PPB < n_pairs ? PPB : n_pairs - p0);   // pairs of this block
+    const uint32_t blk_lo = off[p0], span = off[p0 + np] - blk_lo;   // uniform
+    bool work = false;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const uint32_t i = u * 256 + tid;
+        const uint32_t lo = off[p0 + (i < np ? i : np)], hi = off[p0 + (i + 1 < np ? i + 1 : np)];
+        edge[i] = lo - blk_lo;
+        work |= hi - lo >= 2u;
     }
+    if (tid == 0) edge[PPB] = span;
+    if (!__syncthreads_or(work)) return;
     if (span > stage) {
-        for (uint32_t k = lo + 1; k < hi; ++k) {
-            const int32_t id = ids[k];
-            const float d = DATA ? data[k] : 0.0f;
-            uint32_t s = k;
-            while (s > lo && ids[s - 1] > id) {
-                ids[s] = ids[s - 1];
-                if constexpr (DATA) data[s] = data[s - 1];
-                --s;
-            }
-            if (s != k) {
-                ids[s] = id;
-                if constexpr (DATA) data[s] = d;
+#pragma unroll 1
+        for (int u = 0; u < PPT; ++u) {
+            const uint32_t i = u * 256 + tid;
+            const uint32_t lo = blk_lo + edge[i], hi = blk_lo + edge[i + 1];
+            for (uint32_t k = lo + 1; k < hi; ++k) {
+                const int32_t id = ids[k];
+                const float d = DATA ? data[k] : 0.0f;
+                uint32_t s = k;
+                while (s > lo && ids[s - 1] > id) {
+                    ids[s] = ids[s - 1];
+                    if constexpr (DATA) data[s] = data[s - 1];
+                    --s;
+                }
+                if (s != k) {
+                    ids[s] = id;
+                    if constexpr (DATA) data[s] = d;
+                }
             }
         }
         return;
     }
-    if (!__syncthreads_or(hi - lo >= 2u)) return;
     // eight loads in flight a thread: with one, a block's few thousand bytes arrive at the latency of memory
     for (uint32_t base = 0; base < span; base += 8 * 256) {
         uint32_t key[8], val[8];
@@ -673,13 +571,16 @@ __global__ __launch_bounds__(256) void k_sort_pairs_staged(const uint32_t* __res
             }
         }
     }
-    edge[tid] = (p0 + tid < n_pairs ? lo : off[p1]) - blk_lo;
-    if (tid == 0) edge[256] = span;
-    for (uint32_t e = lo - blk_lo; e < hi - blk_lo; ++e) owner[e] = (unsigned char)tid;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const uint32_t i = u * 256 + tid;
+        for (uint32_t e = edge[i]; e < edge[i + 1]; ++e) owner[e] = (own_t)i;
+    }
     __syncthreads();
     for (uint32_t e = tid; e < span; e += 256) {
         const uint32_t p = owner[e];
         const uint32_t l0 = edge[p], l1 = edge[p + 1];
+        if (l1 - l0 < 2u) continue;
         const kv_t x = kv[e];
         uint32_t at = l0;
         for (uint32_t k = l0; k < l1; ++k) at += kv[k] < x ? 1u : 0u;
@@ -692,6 +593,10 @@ __global__ __launch_bounds__(256) void k_sort_pairs_staged(const uint32_t* __res
             }
         }
     }
+}
+
+size_t sort_stage_lds(uint32_t stage, bool with_data, int ppt) {
+    return (size_t)stage * (with_data ? 8 : 4) + (size_t)(256 * ppt + 1) * 4 + (size_t)stage * (ppt == 1 ? 1 : 2);
 }
 
 size_t lds_bytes(uint32_t width, int tile = 64) {
@@ -801,32 +706,26 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     SDRB_HIP(hipGetLastError());
     if (fill) {
         const uint64_t pairs = (uint64_t)na * nb;
-        // expected matches per pair: sparse results sort four pairs per thread
+        // expected matches per pair: sparse results take four times as many pairs a block
         const double expected = (double)a->nnz / (double)na * ((double)b->nnz / (double)nb) / (double)width;
         const int ppt = expected < 1.5 ? 4 : 1;
         const dim3 sort_grid((uint32_t)((pairs + 256ull * ppt - 1) / (256ull * ppt)));
         int32_t* const sort_ids = out_ids;
-        float* const sort_data = math == kKeepAll ? nullptr : out_data;
-        // pairs of several elements: staged in LDS (one coalesced pass); sparse results: four pairs a thread in place
-        const dim3 staged_grid((uint32_t)((pairs + 255) / 256));
-        // room for the expected id matches of 256 pairs and a sixth more (payload rules only drop matches; a block
-        // that holds more still sorts, in place), 2048 or 4096 elements: a smaller stage lets more blocks share a
-        // compute unit
-        const uint32_t stage = expected * 300.0 <= 2048.0 ? 2048u : 4096u;
-        const size_t kv_bytes = math == kKeepAll ? 4 : 8;
-        const size_t sort_lds = (size_t)stage * (kv_bytes + 1) + 257 * 4;
-        if (ppt == 1 && math == kKeepAll)
-            hipLaunchKernelGGL((k_sort_pairs_staged<false>), staged_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
+        const bool with_data = math != kKeepAll;
+        float* const sort_data = with_data ? out_data : nullptr;
+        // room for the expected id matches of a block's pairs and a sixth more (payload rules only drop matches; a
+        // block that holds more still sorts, in place), 2048 or 4096 elements: a smaller stage lets more blocks share
+        // a compute unit
+        const uint32_t stage = expected * 300.0 * ppt <= 2048.0 ? 2048u : 4096u;
+        const size_t sort_lds = sort_stage_lds(stage, with_data, ppt);
+        if (ppt == 1 && !with_data)
+            hipLaunchKernelGGL((k_sort_pairs_staged<false, 1>), sort_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
         else if (ppt == 1)
-            hipLaunchKernelGGL((k_sort_pairs_staged<true>), staged_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
-        else if (math == kKeepAll && ppt == 4)
-            hipLaunchKernelGGL((k_sort_pairs<false, 4>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
-        else if (math == kKeepAll)
-            hipLaunchKernelGGL((k_sort_pairs<false, 1>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
-        else if (ppt == 4)
-            hipLaunchKernelGGL((k_sort_pairs<true, 4>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
+            hipLaunchKernelGGL((k_sort_pairs_staged<true, 1>), sort_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
+        else if (!with_data)
+            hipLaunchKernelGGL((k_sort_pairs_staged<false, 4>), sort_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
         else
-            hipLaunchKernelGGL((k_sort_pairs<true, 1>), sort_grid, dim3(256), 0, stream, out_off, pairs, sort_ids, sort_data);
+            hipLaunchKernelGGL((k_sort_pairs_staged<true, 4>), sort_grid, dim3(256), sort_lds, stream, out_off, pairs, sort_ids, sort_data, stage);
         SDRB_HIP(hipGetLastError());
     }
     return SDRB_OK;
