@@ -168,11 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                     if constexpr (NEED_B) vb = b_data[beg + e];
                 }
             };
-            auto visit_pass = [&](uint32_t s0, uint32_t id, float vb) {
-                const uint32_t e = (s0 + lane) / LPE;
-                uint32_t jl = r0;
-#pragma unroll
-                for (int r = 1; r < kRowsPerWave; ++r) jl += e >= edge[r] - beg ? 1u : 0u;
+            auto visit_elem = [&](uint32_t id, float vb, uint32_t jl) {
                 uint32_t m, below = 0;   // below: set bits of the element's mask that other lanes visit first
                 if constexpr (LPE == 2) {
                     const uint2 both = *reinterpret_cast<const uint2*>(&mask[id]);
@@ -200,11 +196,64 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                     }
                 }
             };
+            auto visit_pass = [&](uint32_t s0, uint32_t id, float vb) {
+                const uint32_t e = (s0 + lane) / LPE;
+                uint32_t jl = r0;
+#pragma unroll
+                for (int r = 1; r < kRowsPerWave; ++r) jl += e >= edge[r] - beg ? 1u : 0u;
+                visit_elem(id, vb, jl);
+            };
+            // Fill with 32-row tiles: the wave takes rows w, 16 + w, 32 + w, 48 + w of the group instead of four
+            // neighbours, so that at any time the block's sixteen waves write the results of sixteen neighbouring rows
+            // of B.  A 128-byte line of the result holds the elements of about seven neighbouring pairs; written this
+            // way it is complete before L2 gives it up, and the kernel writes 0.31 GB to HBM at config 4 instead of
+            // 1.06 GB in partly filled lines (the elements themselves are 0.30 GB).  Needs every row of the group to
+            // fit PPR passes; the block votes, since all its waves must deal the rows the same way.
+            bool stepped = false;
+            if constexpr (FILL && LPE == 1) {
+                constexpr int PPR = 6;   // passes a row: rows of up to 384 elements
+                const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+                uint32_t rbeg[kRowsPerWave], rlen[kRowsPerWave];
+                bool fits = true;
+#pragma unroll
+                for (int r = 0; r < kRowsPerWave; ++r) {
+                    const uint32_t j = j0 + (uint32_t)kWaves * r + wv;
+                    rbeg[r] = b_off[j < nb ? j : nb];
+                    rlen[r] = j < nb ? b_off[j + 1] - rbeg[r] : 0u;
+                    fits = fits && rlen[r] <= (uint32_t)PPR * 64u;
+                }
+                if (__syncthreads_and(fits ? 1 : 0)) {   // every wave of the block takes the same rows
+                    uint32_t held_id[kRowsPerWave * PPR];
+                    float held_vb[kRowsPerWave * PPR];
+#pragma unroll
+                    for (int r = 0; r < kRowsPerWave; ++r) {
+#pragma unroll
+                        for (int k = 0; k < PPR; ++k) {
+                            const uint32_t e = (uint32_t)k * 64u + lane;
+                            held_id[r * PPR + k] = width;
+                            held_vb[r * PPR + k] = 0.0f;
+                            if (e < rlen[r]) {
+                                held_id[r * PPR + k] = (uint32_t)b_ids[rbeg[r] + e];
+                                if constexpr (NEED_B) held_vb[r * PPR + k] = b_data[rbeg[r] + e];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < kRowsPerWave; ++r) {
+#pragma unroll
+                        for (int k = 0; k < PPR; ++k)
+                            if ((uint32_t)k * 64u < rlen[r]) visit_elem(held_id[r * PPR + k], held_vb[r * PPR + k], (uint32_t)kWaves * r + wv);
+                    }
+                    stepped = true;
+                }
+            }
             // The fill stores inside the bit loop, and on this hardware a wait for a load also waits for
             // every store issued before it: when the wave's elements fit NP registers per lane they are
             // all fetched before the first store, so that nothing waits for a store until the group ends.
             constexpr int NP = FILL ? (TILE == 32 ? 24 : 8) : 0;
-            if (FILL && LPE * n <= (uint32_t)NP * 64u) {
+            if (stepped) {
+                // the group's rows were dealt above
+            } else if (FILL && LPE * n <= (uint32_t)NP * 64u) {
                 uint32_t held_id[NP ? NP : 1];
                 float held_vb[NP ? NP : 1];
 #pragma unroll
