@@ -261,6 +261,40 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass)
                     if ((uint32_t)pass * 64u < LPE * n) visit_pass((uint32_t)pass * 64u, held_id[pass], held_vb[pass]);
+            } else if (!FILL) {
+                // Size ops: the elements of four passes are requested ahead of the pass being walked.  With one
+                // pass ahead a wave has 512 bytes in flight and the sixteen waves of a compute unit stream B at the
+                // latency of memory (config 4: 0.22 ms for the loads alone, 0.11 ms this way).  The loads go
+                // through bounds-checked buffers over the wave's piece and are issued unconditionally (slots past
+                // the end read as zero): inside a branch the compiler would wait for ALL loads in flight at every
+                // use instead of the oldest.
+                constexpr int D = 4;
+                __amdgpu_buffer_rsrc_t ids_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<int32_t*>(b_ids) + beg, 0, (int)(n * 4u), 0x00020000);
+                __amdgpu_buffer_rsrc_t val_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(b_data) + (NEED_B ? beg : 0u), 0, NEED_B ? (int)(n * 4u) : 0, 0x00020000);
+                auto fetch_ahead = [&](uint32_t s0, uint32_t& id, float& vb) {
+                    const uint32_t e = (s0 + lane) / LPE;
+                    id = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ids_rsrc, (int)(e * 4u), 0, 0);
+                    vb = 0.0f;
+                    if constexpr (NEED_B)
+                        vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, (int)(e * 4u), 0, 0));
+                };
+                uint32_t ahead_id[D];
+                float ahead_vb[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) fetch_ahead((uint32_t)k * 64u, ahead_id[k], ahead_vb[k]);
+#pragma unroll 1
+                for (uint32_t s0 = 0; s0 < LPE * n; s0 += D * 64u) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const uint32_t s = s0 + (uint32_t)k * 64u;
+                        const uint32_t id = (s + lane) / LPE < n ? ahead_id[k] : width;   // past the end: the sentinel id
+                        const float vb = ahead_vb[k];
+                        fetch_ahead(s + (uint32_t)D * 64u, ahead_id[k], ahead_vb[k]);
+                        if (s < LPE * n) visit_pass(s, id, vb);
+                    }
+                }
             } else {
                 uint32_t id, nxt_id = width;
                 float vb, nxt_vb = 0.0f;
