@@ -131,13 +131,30 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     const uint32_t n_groups = (nb + kGroup - 1) / kGroup;
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t j0 = g * kGroup;
-        if constexpr (FILL) {   // the tile of output positions of this group's pairs
-            for (uint32_t e = tid; e < kTile * kGroup; e += kBlock) {
+        // Fill: the tile of output positions of this group's pairs.  The offsets are requested here and put into
+        // the tile by start_cursors(), which the walk calls once its own loads are on their way -- so that a group
+        // waits once for memory, not once for the offsets and once more for its rows.
+        constexpr int kInit = FILL ? kTile * kGroup / kBlock : 1;
+        uint32_t init_off[kInit];
+        if constexpr (FILL) {
+#pragma unroll
+            for (int u = 0; u < kInit; ++u) {
+                const uint32_t e = (uint32_t)u * kBlock + tid;
                 const uint32_t q = e / kGroup, jl = e % kGroup;
-                if (q < rows_a && j0 + jl < nb) cnt[jl * kCntLd + q] = out_off[(uint64_t)(i0 + q) * nb + j0 + jl];
+                init_off[u] = 0;
+                if (q < rows_a && j0 + jl < nb) init_off[u] = out_off[(uint64_t)(i0 + q) * nb + j0 + jl];
             }
-            __syncthreads();
         }
+        auto start_cursors = [&]() {
+            if constexpr (FILL) {
+#pragma unroll
+                for (int u = 0; u < kInit; ++u) {
+                    const uint32_t e = (uint32_t)u * kBlock + tid;
+                    cnt[(e % kGroup) * kCntLd + e / kGroup] = init_off[u];
+                }
+                __syncthreads();
+            }
+        };
         if constexpr (FLAT) {
             // The four rows of a wave are one contiguous piece of B's element arrays: its elements are
             // dealt to the lanes, one lane per 32 bits of the mask (two lanes per element with 64-row
@@ -238,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                             }
                         }
                     }
+                    start_cursors();
 #pragma unroll
                     for (int r = 0; r < kRowsPerWave; ++r) {
 #pragma unroll
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                     stepped = true;
                 }
             }
+            if (!stepped) start_cursors();
             // The fill stores inside the bit loop, and on this hardware a wait for a load also waits for
             // every store issued before it: when the wave's elements fit NP registers per lane they are
             // all fetched before the first store, so that nothing waits for a store until the group ends.
@@ -311,6 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                 }
             }
         } else {
+            start_cursors();
             // Rows of up to 64*NIT elements travel HBM -> registers whole (bounds-checked buffer loads, all
             // chunks issued back to back), and the next row is requested before the current one is
             // processed, so a wave keeps two rows in flight; NIT == 0 streams longer rows chunk by chunk.
