@@ -129,20 +129,32 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
 
     const float* val_tile = NEED_A && !FLAT ? a_val_dense + (uint64_t)i0 * width : nullptr;
     const uint32_t n_groups = (nb + kGroup - 1) / kGroup;
+    // Fill with rows dealt 16 apart: the next group's row extents and output offsets are requested before the walk
+    // of this one (before its first store), so that the next group starts with its rows' loads at once.
+    constexpr int kInit = FILL ? kTile * kGroup / kBlock : 1;
+    uint32_t next_off[kInit], next_beg[kRowsPerWave], next_len[kRowsPerWave];
+    bool have_next = false;
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t j0 = g * kGroup;
         // Fill: the tile of output positions of this group's pairs.  The offsets are requested here and put into
         // the tile by start_cursors(), which the walk calls once its own loads are on their way -- so that a group
         // waits once for memory, not once for the offsets and once more for its rows.
-        constexpr int kInit = FILL ? kTile * kGroup / kBlock : 1;
         uint32_t init_off[kInit];
-        if constexpr (FILL) {
+        auto request_offsets = [&](uint32_t first_row, uint32_t (&dst)[kInit]) {
 #pragma unroll
             for (int u = 0; u < kInit; ++u) {
                 const uint32_t e = (uint32_t)u * kBlock + tid;
                 const uint32_t q = e / kGroup, jl = e % kGroup;
-                init_off[u] = 0;
-                if (q < rows_a && j0 + jl < nb) init_off[u] = out_off[(uint64_t)(i0 + q) * nb + j0 + jl];
+                dst[u] = 0;
+                if (q < rows_a && first_row + jl < nb) dst[u] = out_off[(uint64_t)(i0 + q) * nb + first_row + jl];
+            }
+        };
+        if constexpr (FILL) {
+            if (have_next) {
+#pragma unroll
+                for (int u = 0; u < kInit; ++u) init_off[u] = next_off[u];
+            } else {
+                request_offsets(j0, init_off);
             }
         }
         auto start_cursors = [&]() {
@@ -231,14 +243,27 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                 constexpr int PPR = 6;   // passes a row: rows of up to 384 elements
                 const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
                 uint32_t rbeg[kRowsPerWave], rlen[kRowsPerWave];
+                auto request_extents = [&](uint32_t first_row, uint32_t (&rb)[kRowsPerWave], uint32_t (&rl)[kRowsPerWave]) {
+#pragma unroll
+                    for (int r = 0; r < kRowsPerWave; ++r) {
+                        const uint32_t j = first_row + (uint32_t)kWaves * r + wv;
+                        rb[r] = b_off[j < nb ? j : nb];
+                        rl[r] = j < nb ? b_off[j + 1] - rb[r] : 0u;
+                    }
+                };
+                if (have_next) {
+#pragma unroll
+                    for (int r = 0; r < kRowsPerWave; ++r) {
+                        rbeg[r] = next_beg[r];
+                        rlen[r] = next_len[r];
+                    }
+                } else {
+                    request_extents(j0, rbeg, rlen);
+                }
+                have_next = false;
                 bool fits = true;
 #pragma unroll
-                for (int r = 0; r < kRowsPerWave; ++r) {
-                    const uint32_t j = j0 + (uint32_t)kWaves * r + wv;
-                    rbeg[r] = b_off[j < nb ? j : nb];
-                    rlen[r] = j < nb ? b_off[j + 1] - rbeg[r] : 0u;
-                    fits = fits && rlen[r] <= (uint32_t)PPR * 64u;
-                }
+                for (int r = 0; r < kRowsPerWave; ++r) fits = fits && rlen[r] <= (uint32_t)PPR * 64u;
                 if (__syncthreads_and(fits ? 1 : 0)) {   // every wave of the block takes the same rows
                     uint32_t held_id[kRowsPerWave * PPR];
                     float held_vb[kRowsPerWave * PPR];
@@ -254,6 +279,11 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                                 if constexpr (NEED_B) held_vb[r * PPR + k] = b_data[rbeg[r] + e];
                             }
                         }
+                    }
+                    if (g + gridDim.x < n_groups) {   // uniform
+                        request_extents((g + gridDim.x) * kGroup, next_beg, next_len);
+                        request_offsets((g + gridDim.x) * kGroup, next_off);
+                        have_next = true;
                     }
                     start_cursors();
 #pragma unroll
