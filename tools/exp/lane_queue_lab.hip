@@ -17,6 +17,9 @@
 // a line of its own -- and the walk itself (two LDS round trips a match, ~10 LDS instructions a turn of the bit loop,
 // 16 waves sharing one LDS pipe) takes as long as the product's fill.  What would beat both is an output staged in
 // LDS in destination order and copied out as whole lines, which at this width the tables leave no room for.
+// (A further timing-only switch that skipped the ring WRITES as well made the final flush store to whatever positions LDS
+// held and faulted the GPU once; it was removed.  Timing-only builds here may drop stores and reads, never the writes
+// that later addresses are read from.)
 #include <type_traits>
 
 #include "match_math.h"
