@@ -654,6 +654,30 @@ __global__ __launch_bounds__(256) void k_sort_pairs_staged(const uint32_t* __res
     const uint64_t p0 = (uint64_t)blockIdx.x * PPB;
     const uint32_t np = (uint32_t)(p0 + PPB < n_pairs ? PPB : n_pairs - p0);   // pairs of this block
     const uint32_t blk_lo = off[p0], span = off[p0 + np] - blk_lo;   // uniform
+    // The first elements are requested together with the pairs' offsets, before it is known whether any pair of the
+    // block needs sorting: one wait for memory instead of two (eight loads in flight a thread: with one, a block's
+    // few thousand bytes arrive at the latency of memory).
+    const bool staged = span <= stage;
+    uint32_t key[8], val[8];
+    auto request = [&](uint32_t base) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t e = base + u * 256 + tid;
+            key[u] = e < span ? (uint32_t)ids[blk_lo + e] : 0u;
+            val[u] = (DATA && e < span) ? __float_as_uint(data[blk_lo + e]) : 0u;
+        }
+    };
+    auto stage_them = [&](uint32_t base) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t e = base + u * 256 + tid;
+            if (e < span) {
+                if constexpr (DATA) kv[e] = ((unsigned long long)(key[u] ^ 0x80000000u) << 32) | val[u];
+                else kv[e] = key[u] ^ 0x80000000u;
+            }
+        }
+    };
+    if (staged) request(0);
     bool work = false;
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
@@ -686,23 +710,10 @@ __global__ __launch_bounds__(256) void k_sort_pairs_staged(const uint32_t* __res
         }
         return;
     }
-    // eight loads in flight a thread: with one, a block's few thousand bytes arrive at the latency of memory
-    for (uint32_t base = 0; base < span; base += 8 * 256) {
-        uint32_t key[8], val[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t e = base + u * 256 + tid;
-            key[u] = e < span ? (uint32_t)ids[blk_lo + e] : 0u;
-            val[u] = (DATA && e < span) ? __float_as_uint(data[blk_lo + e]) : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t e = base + u * 256 + tid;
-            if (e < span) {
-                if constexpr (DATA) kv[e] = ((unsigned long long)(key[u] ^ 0x80000000u) << 32) | val[u];
-                else kv[e] = key[u] ^ 0x80000000u;
-            }
-        }
+    stage_them(0);
+    for (uint32_t base = 8 * 256; base < span; base += 8 * 256) {
+        request(base);
+        stage_them(base);
     }
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
