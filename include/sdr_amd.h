@@ -112,9 +112,20 @@ int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out
  * below the relevance threshold are kept as they are, exactly like the reference's
  * iterator constructor and push_back (SDR.hpp:83,612-637,1614-1628).
  * Synchronises: the host buffers may be reused on return.
+ * Large batches are checked and staged by a team of host threads (at most 16, or SDRB_HOST_THREADS) through
+ * page-locked buffers while earlier pieces are already crossing the bus; such a batch, when it is refused, leaves
+ * the handle without rows (small batches are checked before anything is copied and leave the handle as it was).
  */
 int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
                           const int32_t* ids, const float* data, void* stream);
+
+/*
+ * The checks of sdrb_batch_upload_csr on their own, without a device: offsets monotone, rows strictly ascending
+ * (SDR.hpp:679,1621), ids in [0, width) when width > 0, UnitData payloads in [0,1] (UnitData.hpp:15-17), ArithData
+ * payloads finite.  Same status codes and messages as the upload; large arrays are checked by a team of host threads.
+ */
+int sdrb_csr_check(uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids, const float* data, int32_t width,
+                   int data_kind);
 
 /*
  * Same as sdrb_batch_upload_csr for a CSR pack that already lives in this device's memory
@@ -196,7 +207,8 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
  * first call).
  * Limits: sizes that depend on ids alone (`this` EmptyData, or SDRB_OP_OR), 32-bit ids, b with a declared
  * width <= 4096 and rows of at most 64 ids, and rows of a: at most 8192 for widths <= 2048, 4096 for widths
- * <= 4096 (SDRB_ERR_UNSUPPORTED beyond that, before any work is enqueued).  Flags: SDRB_FLAG_SWAP.
+ * <= 4096 (SDRB_ERR_UNSUPPORTED beyond that, before any work is enqueued).  Flags: SDRB_FLAG_SWAP
+ * (SDRB_FLAG_FORCE_BITSLICE is accepted: this entry point has no other kernel).
  * Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two
  * threads) race; issue them on one stream or order them with events.
  */
@@ -354,6 +366,14 @@ int sdrb_free(int device, void* ptr);
 int sdrb_memcpy_h2d(int device, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int sdrb_memcpy_d2h(int device, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int sdrb_stream_sync(int device, void* stream);
+
+/*
+ * Scratch memory is kept per (device, stream) and grows on demand; it is not freed while the stream may be used
+ * again.  An application that creates and destroys streams calls this before it destroys one: the stream is
+ * synchronised and every scratch block kept for it is freed (a later call on a stream with the same handle value
+ * starts with none).  No counterpart in the reference.
+ */
+int sdrb_stream_release(int device, void* stream);
 
 /*
  * CSR database files (host side; no GPU needed except for sdrb_batch_upload_file).  The reference

@@ -22,10 +22,16 @@
 // Link with -lsdr_amd (no HIP headers needed here).  Errors become sdr_amd::Error.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iterator>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -77,6 +83,52 @@ template <typename SDR_t>
 using id_of = typename elem_of<SDR_t>::id_type;
 template <typename SDR_t>
 constexpr bool wide_ids = sizeof(id_of<SDR_t>) > 4;
+
+// number of elements of an SDR: its size() where it has one (SDR.hpp:343-349), else the length of its range
+template <typename S, typename = void>
+struct has_size : std::false_type {};
+template <typename S>
+struct has_size<S, std::void_t<decltype(std::declval<const S&>().size())>> : std::true_type {};
+template <typename S>
+size_t row_len(const S& s) {
+    if constexpr (has_size<S>::value) return static_cast<size_t>(s.size());
+    else return static_cast<size_t>(std::distance(s.cbegin(), s.cend()));
+}
+
+// Rows whose elements lie in memory one after the other as bare ids: SDRElem<int, EmptyData> is four bytes, its id
+// (SDRElem.hpp:78-79, EmptyData.hpp:89-92), so a std::vector of them -- the reference's default container,
+// SDR.hpp:26 -- is a packed int array (the layout README.md:185-202 lets a caller rely on) and a row is copied
+// with one memcpy instead of element by element.
+template <typename SDR_t>
+constexpr bool bare_id_rows() {
+    using Elem = elem_of<SDR_t>;
+    using It = decltype(std::declval<const SDR_t&>().cbegin());
+    return !has_value<data_of<SDR_t>>::value && sizeof(Elem) == sizeof(id_of<SDR_t>) && std::is_standard_layout_v<Elem> &&
+           (std::is_pointer_v<It> || std::is_same_v<It, typename std::vector<Elem>::const_iterator>);
+}
+
+// host threads for packing: SDRB_HOST_THREADS, else the machine's, at most 16
+inline int host_threads(size_t rows) {
+    int n = 0;
+    if (const char* env = std::getenv("SDRB_HOST_THREADS")) n = std::atoi(env);
+    if (n <= 0) {
+        n = static_cast<int>(std::thread::hardware_concurrency());
+        if (n <= 0) n = 1;
+        if (n > 16) n = 16;
+    }
+    const size_t useful = rows / 4096 + 1;   // a thread should have a few thousand rows
+    return static_cast<size_t>(n) > useful ? static_cast<int>(useful) : n;
+}
+
+// runs body(t) for t in [0, threads) on that many threads (the caller's among them)
+template <typename F>
+void on_threads(int threads, F&& body) {
+    std::vector<std::thread> team;
+    team.reserve(threads > 0 ? threads - 1 : 0);
+    for (int t = 1; t < threads; ++t) team.emplace_back([&body, t] { body(t); });
+    body(0);
+    for (std::thread& th : team) th.join();
+}
 
 struct DeviceBuffer {
     int device = 0;
@@ -332,30 +384,100 @@ class SDRBatch {
           view_data_(std::move(o.view_data_)) { o.h_ = nullptr; }
     ~SDRBatch() { sdrb_batch_destroy(h_); }
 
-    // Packs the SDRs of [first, last) by iterating each one (the portable way to read any
-    // container, IDContiguousContainer.hpp:263-303 included).  width = 0: arbitrary ids.
+    // Host CSR of a range of SDRs: what pack() uploads.  The arrays are not value-initialised, so that the
+    // threads that fill them are the first to touch their pages.
+    template <typename Id>
+    struct HostRows {
+        size_t n_rows = 0;
+        uint64_t nnz = 0;
+        std::unique_ptr<uint64_t[]> off;
+        std::unique_ptr<Id[]> ids;
+        std::unique_ptr<float[]> data;   // null without payloads
+    };
+
+    // The SDRs of [first, last) as host CSR, read by iterating each one (the portable way to read any container,
+    // IDContiguousContainer.hpp:263-303 included).  With random-access iterators over the SDRs the work is done
+    // in two passes -- lengths, then elements -- by a team of host threads, each filling the rows of a contiguous
+    // share; a std::vector of bare 4-byte ids is copied row by row with memcpy.  Other iterators are walked once.
+    template <typename Iter>
+    static auto pack_host(Iter first, Iter last) {
+        using SDR_t = std::decay_t<decltype(*first)>;
+        using Data = detail::data_of<SDR_t>;
+        constexpr bool payload = detail::has_value<Data>::value;
+        using Id = std::conditional_t<detail::wide_ids<SDR_t>, int64_t, int32_t>;
+        HostRows<Id> h;
+        constexpr bool random_access =
+            std::is_base_of_v<std::random_access_iterator_tag, typename std::iterator_traits<Iter>::iterator_category>;
+        if constexpr (random_access) {
+            const size_t n = static_cast<size_t>(last - first);
+            h.n_rows = n;
+            h.off.reset(new uint64_t[n + 1]);
+            const int threads = detail::host_threads(n);
+            const size_t share = (n + threads - 1) / threads;
+            detail::on_threads(threads, [&](int t) {
+                const size_t r0 = std::min(n, share * t), r1 = std::min(n, r0 + share);
+                for (size_t r = r0; r < r1; ++r) h.off[r + 1] = detail::row_len(first[r]);
+            });
+            h.off[0] = 0;
+            for (size_t r = 0; r < n; ++r) h.off[r + 1] += h.off[r];
+            h.nnz = h.off[n];
+            h.ids.reset(new Id[h.nnz ? h.nnz : 1]);
+            if constexpr (payload) h.data.reset(new float[h.nnz ? h.nnz : 1]);
+            detail::on_threads(threads, [&](int t) {
+                const size_t r0 = std::min(n, share * t), r1 = std::min(n, r0 + share);
+                for (size_t r = r0; r < r1; ++r) {
+                    const SDR_t& row = first[r];
+                    Id* out = h.ids.get() + h.off[r];
+                    if constexpr (detail::bare_id_rows<SDR_t>() && sizeof(Id) == sizeof(detail::id_of<SDR_t>)) {
+                        const size_t len = static_cast<size_t>(h.off[r + 1] - h.off[r]);
+                        if (len) std::memcpy(out, static_cast<const void*>(&*row.cbegin()), len * sizeof(Id));
+                    } else {
+                        float* pay = payload ? h.data.get() + h.off[r] : nullptr;
+                        for (auto it = row.cbegin(); it != row.cend(); ++it) {
+                            *out++ = static_cast<Id>(it->id());
+                            if constexpr (payload) *pay++ = static_cast<float>(it->data().value());
+                        }
+                    }
+                }
+            });
+        } else {
+            std::vector<uint64_t> off{0};
+            std::vector<Id> ids;
+            std::vector<float> data;
+            for (; first != last; ++first) {
+                for (auto it = first->cbegin(); it != first->cend(); ++it) {
+                    ids.push_back(static_cast<Id>(it->id()));
+                    if constexpr (payload) data.push_back(static_cast<float>(it->data().value()));
+                }
+                off.push_back(ids.size());
+            }
+            h.n_rows = off.size() - 1;
+            h.nnz = ids.size();
+            h.off.reset(new uint64_t[off.size()]);
+            std::memcpy(h.off.get(), off.data(), off.size() * sizeof(uint64_t));
+            h.ids.reset(new Id[ids.size() ? ids.size() : 1]);
+            if (!ids.empty()) std::memcpy(h.ids.get(), ids.data(), ids.size() * sizeof(Id));
+            if constexpr (payload) {
+                h.data.reset(new float[data.size() ? data.size() : 1]);
+                if (!data.empty()) std::memcpy(h.data.get(), data.data(), data.size() * sizeof(float));
+            }
+        }
+        return h;
+    }
+
+    // Packs the SDRs of [first, last) into a device batch (pack_host, then one upload that checks the rows
+    // and moves them through page-locked staging).  width = 0: arbitrary ids.
     // Elements with ids wider than 32 bits (SDRElem<long, ...>) make a batch of 64-bit ids.
     template <typename Iter>
     static SDRBatch pack(Iter first, Iter last, int device = 0, int32_t width = 0, void* stream = nullptr) {
         using SDR_t = std::decay_t<decltype(*first)>;
         using Data = detail::data_of<SDR_t>;
-        constexpr bool payload = detail::has_value<Data>::value;
         constexpr bool wide = detail::wide_ids<SDR_t>;
-        std::vector<uint64_t> off{0};
-        std::vector<std::conditional_t<wide, int64_t, int32_t>> ids;
-        std::vector<float> data;
-        for (; first != last; ++first) {
-            for (auto it = first->cbegin(); it != first->cend(); ++it) {
-                ids.push_back(it->id());
-                if constexpr (payload) data.push_back(static_cast<float>(it->data().value()));
-            }
-            off.push_back(ids.size());
-        }
+        const auto h = pack_host(first, last);
         SDRBatch b(device, width, detail::kind_of<Data>(), wide ? 64 : 32);
-        const float* d = data.empty() ? nullptr : data.data();
-        if constexpr (wide) check(sdrb_batch_upload_csr64(b.h_, off.size() - 1, off.data(), ids.data(), d, stream));
-        else check(sdrb_batch_upload_csr(b.h_, off.size() - 1, off.data(), ids.data(), d, stream));
-        b.n_rows_ = off.size() - 1;
+        if constexpr (wide) check(sdrb_batch_upload_csr64(b.h_, h.n_rows, h.off.get(), h.ids.get(), h.data.get(), stream));
+        else check(sdrb_batch_upload_csr(b.h_, h.n_rows, h.off.get(), h.ids.get(), h.data.get(), stream));
+        b.n_rows_ = h.n_rows;
         return b;
     }
 

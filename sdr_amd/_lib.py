@@ -54,6 +54,7 @@ PROTOTYPES = {
     "sdrb_batch_upload_csr64": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "sdrb_elem_op_fill64": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, _vp, _vp, _vp]),
     "sdrb_batch_upload_csr": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "sdrb_csr_check": (C.c_int, [C.c_uint64, _vp, _vp, _vp, C.c_int32, C.c_int]),
     "sdrb_batch_upload_device_csr": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "sdrb_batch_adopt_device_csr": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_int32]),
     "sdrb_batch_id_span": (C.c_int, [_vp, _i32p, _i32p]),
@@ -92,6 +93,7 @@ PROTOTYPES = {
     "sdrb_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "sdrb_memcpy_d2h": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "sdrb_stream_sync": (C.c_int, [C.c_int, _vp]),
+    "sdrb_stream_release": (C.c_int, [C.c_int, _vp]),
     "sdrb_synth_csr": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _vp, _vp, _vp]),
 }
 

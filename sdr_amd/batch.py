@@ -61,7 +61,10 @@ class ElemResult:
 
     A result made by the single-call path has buffers sized by an upper bound and its element count still on the
     device: ``total``, ``ids`` and ``data`` read that count (one stream synchronisation) the first time they are
-    asked for; ``offsets`` and the untrimmed ``ids_buffer`` / ``data_buffer`` never wait."""
+    asked for; ``offsets`` and the untrimmed ``ids_buffer`` / ``data_buffer`` never wait.  A result whose buffers
+    were sized by an ESTIMATE (ande of a few rows) is computed a second time, with room, if the estimate turns
+    out too small when the count is first read: the two batches must still hold the rows they held at the call
+    (an upload or in-place op in between raises here instead of yielding the result of other data)."""
 
     def __init__(self, na, nb, offsets, ids, data, total=None, total_dev=None, refill=None):
         self.na = na
@@ -123,6 +126,7 @@ class ChunkedElemResult:
     def pair(self, i: int, j: int):
         """Device tensors ``(ids, data)`` of result (i, j)."""
         chunk, r = self.chunk_of(i)
+        chunk.total      # a chunk whose buffers were sized by an estimate is completed first
         lo, hi = (int(x) & 0xFFFFFFFF for x in chunk.offsets[r * self.nb + j: r * self.nb + j + 2].tolist())
         return chunk.ids_buffer[lo:hi], None if chunk.data_buffer is None else chunk.data_buffer[lo:hi]
 
@@ -230,6 +234,7 @@ class SDRBatch:
         self.n_rows = 0
         self.nnz = 0
         self.max_row_len = 0
+        self._generation = 0        # counts the uploads: a result computed lazily checks that its inputs are unchanged
 
     # -- construction -------------------------------------------------------------
     @classmethod
@@ -264,6 +269,7 @@ class SDRBatch:
         elif data is not None:
             raise ValueError("EmptyData batch takes no payloads")
         n_rows = off.size - 1
+        self._generation += 1
         upload = self._lib.sdrb_batch_upload_csr64 if self.id_bits == 64 else self._lib.sdrb_batch_upload_csr
         check(upload(self._h, n_rows, off.ctypes.data_as(C.c_void_p),
                                               ids.ctypes.data_as(C.c_void_p), dptr,
@@ -296,6 +302,7 @@ class SDRBatch:
         elif data is not None:
             raise ValueError("EmptyData batch takes no payloads")
         n_rows = offsets.numel() - 1
+        self._generation += 1
         check(self._lib.sdrb_batch_upload_device_csr(self._h, n_rows, offsets.data_ptr(),
                                                      ids.data_ptr() if ids.numel() else None, dptr,
                                                      _stream_handle(self.device, stream)))
@@ -317,6 +324,7 @@ class SDRBatch:
         if (self.data_kind != DATA_EMPTY) != (data is not None):
             raise ValueError("payload tensor must be given exactly for UnitData batches")
         n_rows, nnz = offsets.numel() - 1, ids.numel()
+        self._generation += 1
         check(self._lib.sdrb_batch_adopt_device_csr(
             self._h, n_rows, nnz, offsets.data_ptr(), ids.data_ptr() if nnz else None,
             data.data_ptr() if (data is not None and nnz) else None, max_row_len, min_id, max_id))
@@ -518,10 +526,9 @@ class SDRBatch:
             chunked = self._elem_op_chunked(op, other, swap, stream, algo, flags)
             if chunked is not None:
                 return chunked
-        few = other if swap else self          # which side holds the few rows is the caller's A
         if (op == OP_AND and not rowwise and algo is None and self.id_bits == 32 and other.id_bits == 32 and pairs
                 and self.n_rows <= 32 and 0 < other.width <= 4096 and other.max_row_len <= 64
-                and self.data_kind != DATA_ARITH and other.data_kind != DATA_ARITH and few is not None):
+                and self.data_kind != DATA_ARITH and other.data_kind != DATA_ARITH):
             # One query, or a handful, against a database: offsets and elements in one enqueue, the element buffers
             # sized by the expected number of matches (ids spread evenly over the width) with room to spare.
             expected = self.nnz * other.nnz / other.width
@@ -538,10 +545,18 @@ class SDRBatch:
                                               tot_t.data_ptr(), s))
                 return off_t, ids_t, data_t, tot_t
 
+            made_from = (self._generation, other._generation)
+
+            def refill(total):
+                if (self._generation, other._generation) != made_from:
+                    raise RuntimeError("this ande result outgrew its estimate-sized buffers and has to be computed again, "
+                                       "but one of its batches has been uploaded into since the call: read .total (or "
+                                       ".ids) of such a result before changing its inputs")
+                return run(total)[:3]
+
             try:
                 off_t, ids_t, data_t, tot_t = run(cap)
-                return ElemResult(self.n_rows, other.n_rows, off_t, ids_t, data_t, total_dev=tot_t,
-                                  refill=lambda total: run(total)[:3])
+                return ElemResult(self.n_rows, other.n_rows, off_t, ids_t, data_t, total_dev=tot_t, refill=refill)
             except _lib.SdrbError as e:
                 if e.code != -5:        # not served (tables too large for LDS): the count / fill protocol below
                     raise
@@ -834,11 +849,9 @@ class SDRBatch:
             raise ValueError("rme of an EmptyData batch yields EmptyData whatever result type is asked for")
         if op == OP_AND:
             res = self._elem_op(op, other.ids_only(stream=stream), False, stream, algo)
-            if isinstance(res, ChunkedElemResult):
-                for c in res.chunks:
-                    c.data_buffer = _torch().ones_like(c.ids_buffer, dtype=_torch().float32)
-            else:
-                res.data_buffer = _torch().ones_like(res.ids_buffer, dtype=_torch().float32)
+            for c in (res.chunks if isinstance(res, ChunkedElemResult) else [res]):
+                c.total     # settles the buffers first (an estimate-sized result may be computed again, with room)
+                c.data_buffer = _torch().ones_like(c.ids_buffer, dtype=_torch().float32)
             return res
         return self.as_unit(stream=stream)._elem_op(OP_OR, other, False, stream, algo)
 

@@ -321,28 +321,41 @@ uint32_t chunks_of(const sdrb_batch* b) { return (uint32_t)((b->width + kChunk -
 
 // builds (or reuses) the fragment-ordered byte matrix of a batch, `n_chunks` chunks wide
 int ensure_dense(const sdrb_batch* b, uint32_t n_chunks, hipStream_t stream) {
-    sdrb_batch* mb = const_cast<sdrb_batch*>(b);
+    sdrb_batch* mb = derived_owner(b);
+    std::lock_guard<std::mutex> lock(derived_mutex());
     if (mb->d_dense8 && mb->dense_chunks == n_chunks) return derived_wait(mb->dense_ready, mb->dense_stream, stream);
     if (mb->d_dense8) {
-        if (mb->dense_stream != stream) SDRB_HIP(hipStreamSynchronize(mb->dense_stream));
-        SDRB_HIP(hipStreamSynchronize(stream));
+        // another chunk count (the batch now meets a partner of another width): calls on any stream may still
+        // read the old matrix, so the device is drained before it goes
+        SDRB_HIP(hipDeviceSynchronize());
         (void)hipFree(mb->d_dense8);
         mb->d_dense8 = nullptr;
     }
     const uint64_t panels = (b->n_rows + kPanel - 1) / kPanel;
     const size_t bytes = (size_t)panels * n_chunks * kPieceVec * 16;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&mb->d_dense8), bytes);
+    uint8_t* dense = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dense), bytes);
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu) for the dense byte matrix failed: %s", bytes, hipGetErrorString(e));
-        mb->d_dense8 = nullptr;
         return SDRB_ERR_HIP;
     }
+    int rc = SDRB_OK;
+    if (hipMemsetAsync(dense, 0, bytes, stream) != hipSuccess) rc = SDRB_ERR_HIP;
+    if (rc == SDRB_OK) {
+        hipLaunchKernelGGL(k_densify, dim3((uint32_t)((b->n_rows + 3) / 4)), dim3(256), 0, stream, b->d_offsets,
+                           b->d_ids, (uint32_t)b->n_rows, n_chunks, dense);
+        if (hipGetLastError() != hipSuccess) rc = SDRB_ERR_HIP;
+    }
+    if (rc == SDRB_OK) rc = derived_built(&mb->dense_ready, &mb->dense_stream, stream);
+    if (rc != SDRB_OK) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(dense);
+        set_error("building the dense byte matrix of a batch failed");
+        return rc;
+    }
     mb->dense_chunks = n_chunks;
-    SDRB_HIP(hipMemsetAsync(mb->d_dense8, 0, bytes, stream));
-    hipLaunchKernelGGL(k_densify, dim3((uint32_t)((b->n_rows + 3) / 4)), dim3(256), 0, stream, b->d_offsets,
-                       b->d_ids, (uint32_t)b->n_rows, n_chunks, mb->d_dense8);
-    SDRB_HIP(hipGetLastError());
-    return derived_built(&mb->dense_ready, &mb->dense_stream, stream);
+    mb->d_dense8 = dense;   // published last: whoever sees the pointer also sees the event of its build
+    return SDRB_OK;
 }
 
 template <int LIST>
@@ -370,7 +383,7 @@ int run(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t excl, uint
     int* partial = static_cast<int*>(workspace(b->device, stream, 4, pbytes));
     if (!partial) return SDRB_ERR_HIP;
     hipLaunchKernelGGL(k_allpairs_mfma<LIST>, dim3(ipanels_pad * splits), dim3(256), 0, stream,
-                       reinterpret_cast<const i32x4*>(a->d_dense8), reinterpret_cast<const i32x4*>(b->d_dense8),
+                       reinterpret_cast<const i32x4*>(derived_owner(a)->d_dense8), reinterpret_cast<const i32x4*>(derived_owner(b)->d_dense8),
                        n_ipanels, n_jpanels, n_chunks, splits, pps, (uint32_t)b->n_rows, (long long)excl, partial);
     SDRB_HIP(hipGetLastError());
     return launch_merge_topk(partial, (uint32_t)a->n_rows, splits, kSubLists, (uint64_t)pps * kPanel, k, out_counts,

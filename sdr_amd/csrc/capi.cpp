@@ -11,8 +11,6 @@
 #include <tuple>
 #include <vector>
 
-#include <rocprofiler-sdk-roctx/roctx.h>
-
 #include "sdrb_internal.h"
 
 namespace sdrb {
@@ -20,27 +18,6 @@ namespace sdrb {
 namespace {
 
 thread_local std::string g_error;
-
-// A named range around the host side of an entry point, for `rocprofv3 --marker-trace`: the kernels an entry
-// point enqueues show up under its name.  Without a profiler attached the two calls do nothing.
-struct TraceRange {
-    explicit TraceRange(const char* name) { (void)roctxRangePushA(name); }
-    ~TraceRange() { (void)roctxRangePop(); }
-    TraceRange(const TraceRange&) = delete;
-    TraceRange& operator=(const TraceRange&) = delete;
-};
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(device) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 // Scratch blocks are keyed by (device, stream, slot): work enqueued on different streams -- or by different
 // host threads, each on its own stream -- never shares a block.  A block that has become too small is retired
@@ -131,7 +108,7 @@ void free_batch_storage(sdrb_batch* b) {
 // Makes room for n_rows rows / nnz elements, keeping the current allocation when it is large
 // enough (repeated uploads of similar batches, e.g. one query batch per step, then cost no
 // hipMalloc/hipFree).  Derived data of the previous content is dropped.
-int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
+int reserve_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) {
     const bool unit = has_payload(b);
     drop_derived(b);
     {
@@ -255,8 +232,7 @@ int check_set_algebra_kinds(const sdrb_batch* a, const sdrb_batch* b, int op) {
     return SDRB_OK;
 }
 
-// A batch seen without its payloads.  Derived data built through the view belongs to the batch it views,
-// so it is handed back.
+// A batch seen without its payloads.  Derived data built through the view is kept by the batch it views.
 struct IdView {
     sdrb_batch v;
     const sdrb_batch* src;
@@ -266,21 +242,11 @@ struct IdView {
         v.owns_storage = false;
         v.narrow = nullptr;          // the twin of a batch of 64-bit ids keeps its payload kind: not this view's twin
         v.d_narrow_ids = nullptr;
-    }
-    ~IdView() {
-        // only what was built through THIS view is handed back (two views of one batch may be alive at once)
-        sdrb_batch* m = const_cast<sdrb_batch*>(src);
-        if (v.d_bitplanes != src->d_bitplanes && v.d_bitplanes) {
-            m->d_bitplanes = v.d_bitplanes;
-            m->bitplanes_ready = v.bitplanes_ready;
-            m->bitplanes_stream = v.bitplanes_stream;
-        }
-        if (v.d_dense8 != src->d_dense8 && v.d_dense8) {
-            m->d_dense8 = v.d_dense8;
-            m->dense_chunks = v.dense_chunks;
-            m->dense_ready = v.dense_ready;
-            m->dense_stream = v.dense_stream;
-        }
+        // bit planes and byte matrix depend on the ids alone: they are those of the batch viewed
+        v.derived_home = derived_owner(s);
+        v.d_bitplanes = nullptr;
+        v.d_dense8 = nullptr;
+        v.bitplanes_ready = v.dense_ready = nullptr;
     }
 };
 
@@ -300,6 +266,22 @@ __global__ __launch_bounds__(256) void k_fill_this_len(const uint32_t* __restric
 
 }  // namespace
 
+std::mutex& derived_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz) { return reserve_storage(b, n_rows, nnz); }
+
+void clear_batch_rows(sdrb_batch* b) {
+    drop_derived(b);
+    b->n_rows = 0;
+    b->nnz = 0;
+    b->max_row_len = 0;
+    b->min_id = 0;
+    b->max_id = -1;
+}
+
 void set_error(const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -315,6 +297,7 @@ void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fr
     if (!g_retired.empty()) reap_retired(device);
     Scratch& s = g_ws[ScratchKey{device, stream, slot}];
     if (s.bytes >= bytes && s.ptr) return s.ptr;
+    const size_t old_bytes = s.bytes;
     if (s.ptr) {
         // kernels already enqueued on this stream may still read the old block: it is freed after them
         Retired r{device, s.ptr, nullptr};
@@ -330,6 +313,7 @@ void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fr
     }
     // grow by at least half so that a sequence of slowly growing requests settles quickly
     size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
+    if (want < old_bytes + old_bytes / 2) want = old_bytes + old_bytes / 2;
     hipError_t e = hipMalloc(&s.ptr, want);
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu) for workspace failed: %s", want, hipGetErrorString(e));
@@ -390,216 +374,6 @@ int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out) {
     const int rc = sdrb_batch_create(device, 0, data_kind, out);
     if (rc == SDRB_OK) (*out)->id_bits = 64;
     return rc;
-}
-
-static int sdrb_batch_upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
-                            const int64_t* ids, const float* data, void* stream) {
-    if (!batch || !row_offsets || batch->id_bits != 64) {
-        set_error("sdrb_batch_upload_csr64: null argument or not a 64-bit batch");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    if (row_offsets[0] != 0) {
-        set_error("row_offsets[0] must be 0");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    const uint64_t nnz = row_offsets[n_rows];
-    if (nnz > 0xFFFFFFFFull || n_rows > 0xFFFFFFFEull) {
-        set_error("batch too large for 32-bit offsets");
-        return SDRB_ERR_OVERFLOW;
-    }
-    const bool payload = has_payload(batch);
-    if (nnz && (!ids || (payload && !data))) {
-        set_error("ids (and payloads of a UnitData batch) must not be null");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    std::vector<uint32_t> off32(n_rows + 1);
-    uint32_t max_len = 0;
-    int64_t lowest = INT64_MAX, highest = INT64_MIN;
-    for (uint64_t r = 0; r < n_rows; ++r) {
-        const uint64_t lo = row_offsets[r], hi = row_offsets[r + 1];
-        if (hi < lo || hi > nnz) {
-            set_error("row_offsets not monotone at row %llu", (unsigned long long)r);
-            return SDRB_ERR_INVALID_ARG;
-        }
-        off32[r] = (uint32_t)lo;
-        if (hi - lo > max_len) max_len = (uint32_t)(hi - lo);
-        for (uint64_t k = lo + 1; k < hi; ++k)
-            if (ids[k] <= ids[k - 1]) {
-                set_error("row %llu is not strictly ascending", (unsigned long long)r);
-                return SDRB_ERR_NOT_ASCENDING;
-            }
-        if (hi > lo) {   // rows ascend: their ends are their extremes
-            if (ids[lo] < lowest) lowest = ids[lo];
-            if (ids[hi - 1] > highest) highest = ids[hi - 1];
-        }
-    }
-    off32[n_rows] = (uint32_t)nnz;
-    if (payload)
-        for (uint64_t k = 0; k < nnz; ++k)
-            if (!(data[k] >= 0.0f && data[k] <= 1.0f)) {
-                set_error("UnitData payload %g at element %llu is outside [0,1]", (double)data[k], (unsigned long long)k);
-                return SDRB_ERR_PAYLOAD_RANGE;
-            }
-    DeviceGuard guard(batch->device);
-    if (!guard.ok) {
-        set_error("hipSetDevice(%d) failed", batch->device);
-        return SDRB_ERR_HIP;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = reserve_batch_storage(batch, n_rows, nnz);
-    if (rc != SDRB_OK) return rc;
-    SDRB_HIP(hipMemcpyAsync(batch->d_offsets, off32.data(), (n_rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    if (nnz && payload) SDRB_HIP(hipMemcpyAsync(batch->d_data, data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
-    SDRB_HIP(hipStreamSynchronize(s));
-    batch->n_rows = n_rows;
-    batch->nnz = nnz;
-    batch->max_row_len = max_len;
-    batch->min_id = 0;
-    batch->max_id = -1;
-    // ids that all fit 32 bits (the reference's SDRElem<long> rows usually do): keep them narrowed as well
-    if (nnz == 0 || (lowest >= INT32_MIN && highest < INT32_MAX)) {
-        std::vector<int32_t> small(nnz);
-        for (uint64_t k = 0; k < nnz; ++k) small[k] = (int32_t)ids[k];
-        if (nnz) {
-            SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&batch->d_narrow_ids), nnz * sizeof(int32_t)));
-            SDRB_HIP(hipMemcpyAsync(batch->d_narrow_ids, small.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            SDRB_HIP(hipStreamSynchronize(s));
-        }
-        sdrb_batch* twin = new sdrb_batch;
-        twin->device = batch->device;
-        twin->data_kind = batch->data_kind;
-        twin->id_bits = 32;
-        twin->width = (nnz && lowest >= 0) ? (int32_t)(highest + 1) : 0;
-        twin->n_rows = n_rows;
-        twin->nnz = nnz;
-        twin->max_row_len = max_len;
-        twin->min_id = nnz ? (int32_t)lowest : 0;
-        twin->max_id = nnz ? (int32_t)highest : -1;
-        twin->d_offsets = batch->d_offsets;
-        twin->d_ids = batch->d_narrow_ids;
-        twin->d_data = batch->d_data;
-        twin->owns_storage = false;
-        batch->narrow = twin;
-    }
-    return SDRB_OK;
-}
-
-int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets, const int64_t* ids, const float* data, void* stream) {
-    TraceRange range("sdrb_batch_upload_csr64");
-    return sdrb::guarded("sdrb_batch_upload_csr64", [&] { return sdrb_batch_upload_csr64_impl(batch, n_rows, row_offsets, ids, data, stream); });
-}
-
-static int sdrb_batch_upload_csr_impl(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
-                          const int32_t* ids, const float* data, void* stream) {
-    if (!batch || !row_offsets) {
-        set_error("sdrb_batch_upload_csr: null argument");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    if (batch->id_bits != 32) {
-        set_error("this batch holds 64-bit ids: use sdrb_batch_upload_csr64");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    if (row_offsets[0] != 0) {
-        set_error("row_offsets[0] must be 0");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    const uint64_t nnz = row_offsets[n_rows];
-    if (nnz > 0xFFFFFFFFull || n_rows > 0xFFFFFFFEull) {
-        set_error("batch too large for 32-bit offsets (%llu rows, %llu elements)",
-                  (unsigned long long)n_rows, (unsigned long long)nnz);
-        return SDRB_ERR_OVERFLOW;
-    }
-    if (nnz > 0 && !ids) {
-        set_error("ids is null");
-        return SDRB_ERR_INVALID_ARG;
-    }
-    const bool unit = has_payload(batch);
-    if (unit && nnz > 0 && !data) {
-        set_error("a batch with payloads needs a payload array");
-        return SDRB_ERR_INVALID_ARG;
-    }
-
-    // validate rows and narrow the offsets
-    std::vector<uint32_t> off32(n_rows + 1);
-    uint32_t max_len = 0;
-    int32_t min_id = 0, max_id = -1;
-    bool any = false;
-    for (uint64_t r = 0; r < n_rows; ++r) {
-        const uint64_t lo = row_offsets[r], hi = row_offsets[r + 1];
-        if (hi < lo || hi > nnz) {
-            set_error("row_offsets not monotone at row %llu", (unsigned long long)r);
-            return SDRB_ERR_INVALID_ARG;
-        }
-        off32[r] = (uint32_t)lo;
-        const uint64_t len = hi - lo;
-        if (len > max_len) max_len = (uint32_t)len;
-        for (uint64_t k = lo; k < hi; ++k) {
-            if (k > lo && ids[k] <= ids[k - 1]) {
-                set_error("row %llu is not strictly ascending at element %llu (%d after %d)",
-                          (unsigned long long)r, (unsigned long long)(k - lo), ids[k], ids[k - 1]);
-                return SDRB_ERR_NOT_ASCENDING;
-            }
-        }
-        if (len) {
-            const int32_t first = ids[lo], last = ids[hi - 1];
-            if (!any || first < min_id) min_id = first;
-            if (!any || last > max_id) max_id = last;
-            any = true;
-        }
-    }
-    off32[n_rows] = (uint32_t)nnz;
-    if (batch->width > 0 && any && (min_id < 0 || max_id >= batch->width)) {
-        set_error("id outside the declared width: ids span [%d, %d], width %d", min_id, max_id,
-                  batch->width);
-        return SDRB_ERR_ID_RANGE;
-    }
-    if (batch->data_kind == SDRB_DATA_ARITH) {
-        // the dot-product kernels rely on finite payloads (a term of an absent id must be a zero)
-        for (uint64_t k = 0; k < nnz; ++k) {
-            if (!std::isfinite(data[k])) {
-                set_error("ArithData payload at element %llu is not finite", (unsigned long long)k);
-                return SDRB_ERR_PAYLOAD_RANGE;
-            }
-        }
-    }
-    if (batch->data_kind == SDRB_DATA_UNIT) {
-        for (uint64_t k = 0; k < nnz; ++k) {
-            if (!(data[k] >= 0.0f && data[k] <= 1.0f)) {
-                set_error("UnitData payload %g at element %llu is outside [0,1]", (double)data[k],
-                          (unsigned long long)k);
-                return SDRB_ERR_PAYLOAD_RANGE;
-            }
-        }
-    }
-
-    DeviceGuard guard(batch->device);
-    if (!guard.ok) {
-        set_error("hipSetDevice(%d) failed", batch->device);
-        return SDRB_ERR_HIP;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    {
-        const int rc = reserve_batch_storage(batch, n_rows, nnz);
-        if (rc != SDRB_OK) return rc;
-    }
-    SDRB_HIP(hipMemcpyAsync(batch->d_offsets, off32.data(), (n_rows + 1) * sizeof(uint32_t),
-                            hipMemcpyHostToDevice, s));
-    if (nnz) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (nnz && unit)
-        SDRB_HIP(hipMemcpyAsync(batch->d_data, data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
-    SDRB_HIP(hipStreamSynchronize(s));
-    batch->n_rows = n_rows;
-    batch->nnz = nnz;
-    batch->max_row_len = max_len;
-    batch->min_id = min_id;
-    batch->max_id = max_id;
-    return SDRB_OK;
-}
-
-int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids, const float* data, void* stream) {
-    TraceRange range("sdrb_batch_upload_csr");
-    return sdrb::guarded("sdrb_batch_upload_csr", [&] { return sdrb_batch_upload_csr_impl(batch, n_rows, row_offsets, ids, data, stream); });
 }
 
 int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint32_t* row_offsets,
@@ -869,7 +643,7 @@ int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_size_op_static");
     if (rc != SDRB_OK) return rc;
     if (flags & ~(SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_BITSLICE)) {
-        set_error("sdrb_size_op_static takes SDRB_FLAG_SWAP only");
+        set_error("sdrb_size_op_static takes SDRB_FLAG_SWAP (and SDRB_FLAG_FORCE_BITSLICE, which it implies) only");
         return SDRB_ERR_INVALID_ARG;
     }
     const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
@@ -1489,6 +1263,27 @@ int sdrb_memcpy_d2h(int device, void* dst_host, const void* src_dev, size_t byte
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (bytes) SDRB_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
     SDRB_HIP(hipStreamSynchronize(s));
+    return SDRB_OK;
+}
+
+int sdrb_stream_release(int device, void* stream) {
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SDRB_HIP(hipStreamSynchronize(s));   // nothing enqueued on the stream reads its scratch any more
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    reap_retired(device);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+        if (it->first.device == device && it->first.stream == s) {
+            if (it->second.ptr) (void)hipFree(it->second.ptr);
+            it = g_ws.erase(it);
+        } else {
+            ++it;
+        }
+    }
     return SDRB_OK;
 }
 

@@ -230,31 +230,11 @@ static int sdrb_file_writer_append_impl(sdrb_file_writer* w, uint64_t n_rows, co
         set_error("sdrb_file_writer_append: element arrays missing");
         return SDRB_ERR_INVALID_ARG;
     }
-    // the same preconditions an upload enforces, so that every file holds a valid batch
-    for (uint64_t r = 0; r < n_rows; ++r) {
-        const uint64_t lo = row_offsets[r], hi = row_offsets[r + 1];
-        if (hi < lo || hi > nnz) {
-            set_error("row_offsets not monotone at row %llu of the chunk", (unsigned long long)r);
-            return SDRB_ERR_INVALID_ARG;
-        }
-        for (uint64_t k = lo; k < hi; ++k) {
-            if (k > lo && ids[k] <= ids[k - 1]) {
-                set_error("row %llu of the chunk is not strictly ascending", (unsigned long long)r);
-                return SDRB_ERR_NOT_ASCENDING;
-            }
-            if (w->width > 0 && (ids[k] < 0 || ids[k] >= w->width)) {
-                set_error("id %d outside the declared width %d", ids[k], w->width);
-                return SDRB_ERR_ID_RANGE;
-            }
-            if (w->unit && !w->arith && !(data[k] >= 0.0f && data[k] <= 1.0f)) {
-                set_error("UnitData payload %g is outside [0,1]", (double)data[k]);
-                return SDRB_ERR_PAYLOAD_RANGE;
-            }
-            if (w->arith && !(data[k] - data[k] == 0.0f)) {
-                set_error("ArithData payload of row %llu of the chunk is not finite", (unsigned long long)r);
-                return SDRB_ERR_PAYLOAD_RANGE;
-            }
-        }
+    // the same preconditions an upload enforces (checked by the same code), so that every file holds a valid batch
+    {
+        const int rc = sdrb::check_host_csr(n_rows, row_offsets, ids, data, w->width,
+                                            !w->unit ? SDRB_DATA_EMPTY : w->arith ? SDRB_DATA_ARITH : SDRB_DATA_UNIT);
+        if (rc != SDRB_OK) return rc;
     }
     if (!write_all(w->fd, ids, nnz * sizeof(int32_t)) ||
         (w->unit && !write_all(w->data_fd, data, nnz * sizeof(float)))) {

@@ -20,6 +20,8 @@
 // total tells the caller, who calls again with room).  Offsets are always complete.
 #include <type_traits>
 
+#include <algorithm>
+
 #include "lane_tiles.h"
 #include "match_math.h"
 #include "sdrb_internal.h"
@@ -361,6 +363,9 @@ bool make_plan(const sdrb_batch* a, const sdrb_batch* b, bool swap, FewPlan* p) 
     p->nch = b->max_row_len <= 40 ? 5 : 8;
     const bool with_vals = p->math == kSelfA || p->math == kMul;
     const uint32_t val_cap = with_vals ? ((uint32_t)kTile * (a->max_row_len ? a->max_row_len : 1u) + 3u) & ~3u : 0u;
+    // col[w] addresses a payload by a 16-bit byte offset into the tile: every payload the tile can hold must lie below 64 KiB
+    const uint64_t most_vals = std::min<uint64_t>(a->nnz, (uint64_t)kTile * a->max_row_len);
+    if (with_vals && mask_bytes((uint32_t)p->wcap) + col_bytes((uint32_t)p->wcap) + 4u * most_vals > 65535u) return false;
     p->tile_bytes = mask_bytes((uint32_t)p->wcap) + col_bytes((uint32_t)p->wcap) + val_cap * 4u + kLenBytes;
     p->lds = (size_t)p->tile_bytes + (size_t)a->n_rows * kBlock * 4u + (size_t)kTile * kWaves * 4u;
     if (p->lds > 160 * 1024 - 512) return false;

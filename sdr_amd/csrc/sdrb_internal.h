@@ -4,11 +4,14 @@
 #include <hip/hip_runtime.h>
 
 #include <exception>
+#include <mutex>
 #include <new>
 
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include "../../include/sdr_amd.h"
 
@@ -33,6 +36,9 @@ struct sdrb_batch {
     // build, and a call on any other stream waits for it before its kernels read the form.
     hipEvent_t bitplanes_ready = nullptr, dense_ready = nullptr;
     hipStream_t bitplanes_stream = nullptr, dense_stream = nullptr;
+    // A temporary view of another batch (the same rows seen without payloads) keeps no derived forms of its own:
+    // they are built in, and read from, the batch it views.
+    sdrb_batch* derived_home = nullptr;
     // A batch of 64-bit ids whose ids all fit 32 bits also keeps them narrowed: `narrow` is a 32-bit batch that
     // views this batch's offsets and payloads and owns only d_narrow_ids (declared width = largest id + 1 when no
     // id is negative), so that two such batches are served by every kernel the 32-bit path has.
@@ -46,6 +52,28 @@ namespace sdrb {
 inline bool has_payload(const sdrb_batch* b) { return b->data_kind != SDRB_DATA_EMPTY; }
 
 void set_error(const char* fmt, ...);
+
+// A named range around the host side of an entry point, for `rocprofv3 --marker-trace`: the kernels an entry
+// point enqueues show up under its name.  Without a profiler attached the two calls do nothing.
+struct TraceRange {
+    explicit TraceRange(const char* name) { (void)roctxRangePushA(name); }
+    ~TraceRange() { (void)roctxRangePop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+
+// makes `device` current for the scope and restores the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 // Runs `body` (a callable returning a status code) so that nothing is thrown through the C ABI: a failed
 // host allocation or any other C++ exception becomes a status code and a message.
@@ -74,6 +102,18 @@ int guarded(const char* what, F&& body) noexcept {
 // *fresh (optional) tells whether the block has just been allocated, i.e. holds nothing of an earlier call.
 void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fresh = nullptr);
 
+// capi.cpp: room for n_rows rows / nnz elements in the batch (the current allocation is kept when it is large
+// enough; derived forms of the previous content are dropped).  The batch's device must be current.
+int reserve_batch_storage(sdrb_batch* b, uint64_t n_rows, uint64_t nnz);
+// the batch holds no rows any more (its storage stays allocated for the next upload)
+void clear_batch_rows(sdrb_batch* b);
+
+// ingest.cpp: the checks of an upload on host CSR (offsets monotone, rows strictly ascending, ids inside `width`
+// when it is > 0, payloads in range), by a team of threads when the arrays are large; row_offsets[0] == 0 and
+// non-null arrays are the caller's business.  Status code and message of the first finding.
+int check_host_csr(uint64_t n_rows, const uint64_t* row_offsets, const int32_t* ids, const float* data, int32_t width,
+                   int data_kind);
+
 #define SDRB_HIP(call)                                                                   \
     do {                                                                                 \
         hipError_t e_ = (call);                                                          \
@@ -83,6 +123,15 @@ void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fr
             return SDRB_ERR_HIP;                                                         \
         }                                                                                \
     } while (0)
+
+// the batch whose handle caches the derived forms of b's rows (b itself unless b is a temporary view)
+inline sdrb_batch* derived_owner(const sdrb_batch* b) {
+    return b->derived_home ? b->derived_home : const_cast<sdrb_batch*>(b);
+}
+// Handles may be read by any number of threads at once, and derived forms are built lazily inside such reads:
+// check, build and publication of a derived form happen under this lock (defined in capi.cpp), the pointer is
+// published after the event that marks the end of the build has been recorded.
+std::mutex& derived_mutex();
 
 // after the build of a derived form has been enqueued on `stream`
 inline int derived_built(hipEvent_t* ready, hipStream_t* built_on, hipStream_t stream) {

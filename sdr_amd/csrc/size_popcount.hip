@@ -116,16 +116,29 @@ bool popcount_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 }
 
 int ensure_bitplanes(const sdrb_batch* b, hipStream_t stream) {
-    sdrb_batch* mb = const_cast<sdrb_batch*>(b);   // derived data cached in the handle
+    sdrb_batch* mb = derived_owner(b);   // derived data cached in the handle
+    std::lock_guard<std::mutex> lock(derived_mutex());
     if (mb->d_bitplanes) return derived_wait(mb->bitplanes_ready, mb->bitplanes_stream, stream);
     const int nw = words_for(b->width);
     const size_t bytes = (size_t)nw * b->n_rows * sizeof(uint32_t);
-    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&mb->d_bitplanes), bytes));
-    SDRB_HIP(hipMemsetAsync(mb->d_bitplanes, 0, bytes, stream));
-    hipLaunchKernelGGL(k_scatter_bitplanes, dim3((uint32_t)((b->n_rows + 3) / 4)), dim3(256), 0, stream,
-                       b->d_offsets, b->d_ids, (uint32_t)b->n_rows, mb->d_bitplanes);
-    SDRB_HIP(hipGetLastError());
-    return derived_built(&mb->bitplanes_ready, &mb->bitplanes_stream, stream);
+    uint32_t* planes = nullptr;
+    SDRB_HIP(hipMalloc(reinterpret_cast<void**>(&planes), bytes));
+    int rc = SDRB_OK;
+    if (hipMemsetAsync(planes, 0, bytes, stream) != hipSuccess) rc = SDRB_ERR_HIP;
+    if (rc == SDRB_OK) {
+        hipLaunchKernelGGL(k_scatter_bitplanes, dim3((uint32_t)((b->n_rows + 3) / 4)), dim3(256), 0, stream,
+                           b->d_offsets, b->d_ids, (uint32_t)b->n_rows, planes);
+        if (hipGetLastError() != hipSuccess) rc = SDRB_ERR_HIP;
+    }
+    if (rc == SDRB_OK) rc = derived_built(&mb->bitplanes_ready, &mb->bitplanes_stream, stream);
+    if (rc != SDRB_OK) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(planes);
+        set_error("building the bit planes of a batch failed");
+        return rc;
+    }
+    mb->d_bitplanes = planes;   // published last: whoever sees the pointer also sees the event of its build
+    return SDRB_OK;
 }
 
 int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
@@ -150,7 +163,7 @@ int launch_size_popcount(const sdrb_batch* a, const sdrb_batch* b, int op, bool 
     SDRB_HIP(hipGetLastError());
 
     Args g;
-    g.planes = b->d_bitplanes;
+    g.planes = derived_owner(b)->d_bitplanes;
     g.a = a;
     g.b = b;
     g.a_bits = a_bits;

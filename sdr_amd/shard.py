@@ -379,7 +379,12 @@ class ShardedDatabase:
         kk = min(k, 16)
         if kk < k:
             return self.topk(self.size_op("ands", queries), k)    # the fused kernel keeps at most 16 per query
-        c, r = self.engine.allpairs_topk(queries, self.shard, kk, -1)
+        try:
+            c, r = self.engine.allpairs_topk(queries, self.shard, kk, -1)
+        except Exception as e:          # shapes the fused kernels do not take (widths beyond 16 384, very long rows)
+            if getattr(e, "code", None) != -5:
+                raise
+            return self.topk(self.size_op("ands", queries.ids_only() if hasattr(queries, "ids_only") else queries), k)
         c, r = c.to(torch.int64), r.to(torch.int64)
         r = torch.where(r >= 0, r + self.row_lo, r)
         c, r = self._gather_candidates(c, r)

@@ -93,3 +93,77 @@ def test_create_rejects_bad_arguments():
     assert lib.sdrb_batch_create(0, 0, 9, C.byref(h)) == -1
     assert lib.sdrb_batch_create(-1, 0, 0, C.byref(h)) == -1
     assert lib.sdrb_batch_destroy(None) == 0
+
+
+def _check_rc(off, ids, data, width, kind):
+    lib = _lib.load()
+    rc = lib.sdrb_csr_check(off.size - 1, off.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                            data.ctypes.data_as(C.c_void_p) if data is not None else None, width, kind)
+    return rc, lib.sdrb_last_error().decode()
+
+
+def test_large_batches_are_checked_by_the_thread_team_like_small_ones(monkeypatch):
+    """sdrb_csr_check runs the checks of an upload without a device.  Arrays of a few megabytes and more go
+    through the team of host threads (pieces of the element arrays handed out in order); the first finding --
+    offsets, then order, then width, then payloads -- must come out whatever the number of threads."""
+    width, active, n = 2048, 40, 300_000      # 48 MB of ids: a dozen pieces
+    off, ids, data = sdr_amd.synth_csr(7, 0, n, width, active, True)
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("SDRB_HOST_THREADS", threads)
+        assert _check_rc(off, ids, data, width, 1)[0] == 0
+        assert _check_rc(off, ids, None, width, 0)[0] == 0
+        # a descent inside one row, far into the arrays; an equal neighbour elsewhere, later
+        bad = ids.copy()
+        r = 217_123
+        bad[r * active + 7] = bad[r * active + 6]
+        bad[(r + 5000) * active + 1] = bad[(r + 5000) * active]
+        rc, msg = _check_rc(off, bad, data, width, 1)
+        assert rc == -2 and f"row {r} " in msg and "element 7" in msg, msg
+        # the last id of a row above the first of the next is fine; above the width it is not
+        bad = ids.copy()
+        bad[(r + 1) * active - 1] = width + 5
+        rc, msg = _check_rc(off, bad, data, width, 1)
+        assert rc == -3 and str(width + 5) in msg, msg
+        assert _check_rc(off, bad, data, 0, 1)[0] == 0
+        bad = ids.copy()
+        bad[0] = -3
+        assert _check_rc(off, bad, None, width, 0)[0] == -3
+        assert _check_rc(off, bad, None, 0, 0)[0] == 0
+        # payloads: the first bad one is named; order findings come first
+        pd = data.copy()
+        pd[9_000_017] = 1.25
+        pd[11_000_000] = np.nan
+        rc, msg = _check_rc(off, ids, pd, width, 1)
+        assert rc == -7 and "9000017" in msg, msg
+        assert _check_rc(off, ids, pd, width, 2)[0] == -7          # ArithData: the NaN
+        pd[11_000_000] = 3.0
+        assert _check_rc(off, ids, pd, width, 2)[0] == 0           # ArithData takes any finite value
+        bad = ids.copy()
+        bad[11_500_001] = bad[11_500_000]                          # the first two ids of a row
+        rc, msg = _check_rc(off, bad, pd, width, 1)
+        assert rc == -2, msg
+        # offsets: not monotone, beyond the arrays
+        boff = off.copy()
+        boff[123_456] = boff[123_457] + 1
+        rc, msg = _check_rc(boff, ids, data, width, 1)
+        assert rc == -1 and "row 123456" in msg, msg
+        boff = off.copy()
+        boff[n - 1] = off[n] + 40
+        assert _check_rc(boff, ids, data, width, 1)[0] == -1
+    # ragged rows with empty ones between: row starts are where descents are allowed
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 90, size=200_000)
+    lens[rng.integers(0, lens.size, size=20_000)] = 0
+    roff = np.zeros(lens.size + 1, dtype=np.uint64)
+    roff[1:] = np.cumsum(lens)
+    steps = rng.integers(1, 40, size=int(roff[-1])).astype(np.int64)
+    flat = np.cumsum(steps)
+    starts = np.repeat(flat[np.minimum(roff[:-1], flat.size - 1).astype(np.int64)] - 1, lens)
+    rids = (flat - starts).astype(np.int32)                         # every row restarts near 1 and ascends
+    assert _check_rc(roff, rids, None, 0, 0)[0] == 0
+    row = 150_000 + int(np.argmax(lens[150_000:] >= 2))             # a row with a second element to spoil
+    first = int(roff[row])
+    rids2 = rids.copy()
+    rids2[first + 1] = rids2[first]
+    rc, msg = _check_rc(roff, rids2, None, 0, 0)
+    assert rc == -2 and f"row {row} " in msg, msg

@@ -731,3 +731,48 @@ def test_fused_few_rows_ande_refills_when_the_estimate_is_too_small():
     res = dev(t, 2048).ande(dev(a, 2048))
     assert res.total == 4 * 600 * 40 and res.ids.numel() == res.total
     assert_elems_equal(res.to_host(), oracle.port().elem_op(AND, t, a))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["UU", "UE"])
+@pytest.mark.parametrize("len_t,fused", [(310, True), (450, False)])
+def test_few_rows_ande_with_more_payloads_than_16_bit_offsets_reach(name, len_t, fused):
+    """The fused few-rows path finds a payload of A through a 16-bit byte offset into its tile.  32 UnitData rows of
+    310 ids at width 4096 stay below 64 KiB (fused path); 32 rows of 450 ids do not: the entry point refuses them and
+    ande takes another kernel -- equal to the oracle either way."""
+    tu, au = PAIRINGS[name]
+    width = 4096
+    off_t, ids_t, data_t = sdr_amd.synth_csr(21, 0, 32, width, len_t, True)
+    off_a, ids_a, data_a = sdr_amd.synth_csr(22, 0, 900, width, 64, au)
+    t, a = Batch(off_t, ids_t, data_t), Batch(off_a, ids_a, data_a)
+    dt, da = dev(t, width), dev(a, width)
+    res = dt.ande(da)
+    assert (res._total_dev is not None) == fused
+    assert_elems_equal(res.to_host(), oracle.port().elem_op(AND, t, a))
+    if not fused:
+        import torch
+        from sdr_amd import _lib
+        total = torch.zeros(1, dtype=torch.int64, device="cuda")
+        offs = torch.zeros(32 * 900 + 1, dtype=torch.int32, device="cuda")
+        rc = _lib.load().sdrb_ande_few(dt._h, da._h, 0, offs.data_ptr(), None, None, 0, total.data_ptr(), None)
+        assert rc == -5
+
+
+@pytest.mark.gpu
+def test_estimate_sized_ande_result_and_changed_inputs():
+    """A few-rows ande result whose estimate was too small is computed again when its count is first read -- from
+    the batches as they are THEN.  An upload in between must not yield the result of other data; with ret="unit" the
+    ones are as long as the ids."""
+    ids = np.tile(np.arange(100, 140, dtype=np.int32), 600)
+    off = np.arange(601, dtype=np.uint64) * 40
+    t, a = Batch(off[:5], ids[: 4 * 40], None), Batch(off, ids, None)
+    dt, da = dev(t, 2048), dev(a, 2048)
+    res = dt.ande(da)
+    da.upload(off[:301], ids[: 300 * 40])
+    with pytest.raises(RuntimeError):
+        res.total
+    da.upload(off, ids)
+    res = dt.ande(da, ret="unit")
+    assert res.total == 4 * 600 * 40 and res.ids.numel() == res.total and res.data.numel() == res.total
+    assert bool((res.data == 1.0).all())
+    assert_elems_equal((res.to_host()[0], res.to_host()[1], None), oracle.port().elem_op(AND, t, a))

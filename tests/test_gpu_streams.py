@@ -117,3 +117,44 @@ def test_offsets_scan_long_odd_and_unaligned():
         got = view.cpu().numpy().view(np.uint32).astype(np.uint64)
         assert int(total.value) == int(want[-1])
         assert np.array_equal(got, want)
+
+
+def test_first_use_of_a_derived_form_from_two_host_threads():
+    """The popcount kernel and the matrix-core all-pairs kernel build a form of the batch inside the first call that
+    needs it and cache it in the handle.  Two host threads whose FIRST such calls on one handle coincide must both get
+    right answers (the build is published under a lock, after the event that marks its end)."""
+    import torch
+
+    import oracle
+    from sdr_amd import SDRBatch
+
+    width, d_csr, qa_csr, qb_csr = _inputs()
+    od = oracle.Batch(*d_csr)
+    want = {"a": oracle.port().size_op(0, oracle.Batch(*qa_csr), od), "b": oracle.port().size_op(0, oracle.Batch(*qb_csr), od)}
+    for attempt in range(6):
+        d = SDRBatch.from_csr(*d_csr, width=width)       # a fresh handle: nothing derived yet
+        start = threading.Barrier(2)
+        results, errors = {}, []
+
+        def work(name, q_csr):
+            try:
+                torch.cuda.set_device(0)
+                q = SDRBatch.from_csr(*q_csr, width=width)
+                stream = torch.cuda.Stream()
+                start.wait()
+                counts = q.ands(d, stream=stream, algo="popcount")
+                top = q.allpairs_topk(d, 4, stream=stream, algo="mfma")
+                stream.synchronize()
+                results[name] = (counts.cpu().numpy().view(np.uint32), top[0].cpu().numpy(), top[1].cpu().numpy())
+            except Exception as e:      # noqa: BLE001 -- reported by the main thread
+                errors.append((name, repr(e)))
+
+        ta = threading.Thread(target=work, args=("a", qa_csr))
+        tb = threading.Thread(target=work, args=("b", qb_csr))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        assert not errors, errors
+        for name in ("a", "b"):
+            counts, top_c, top_r = results[name]
+            assert np.array_equal(counts, want[name]), (attempt, name)
+            # the matrix-core kernel's best overlap per row is the row maximum of ands
+            assert np.array_equal(top_c[:, 0].astype(np.uint32), want[name].max(axis=1)), (attempt, name)
