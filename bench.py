@@ -177,15 +177,20 @@ def main() -> None:
         ms_per_step = elapsed * 1e3 / args.steps
         kernel_ms = dev_ms / args.steps
         ach = algorithmic_bytes(nq, nd) / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic cannot be counted inside this run (the counters need rocprofv3 passes of their own): the figure
+        # is the one those passes left for this very shape, and `traffic_source` says where it comes from
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("queries") == nq and tj.get("rows") == nd and tj.get("op") == args.op:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = {"file": "profiles/hbm_traffic.json", "tag": tj.get("tag"),
+                                      "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command "
+                                             "(tools/profile_bench.sh), not measured in this run"}
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         line = {
             "metric": "SDR pair-ops/sec (ands, 2048-bit/40-active)",
             "value": pair_ops / elapsed,
@@ -202,7 +207,7 @@ def main() -> None:
                        "queries": nq, "rows_per_gpu": nd, "width": WIDTH, "active": ACTIVE,
                        "sharding": f"rows x{world}, counts stay sharded"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kernel_ms, "algorithmic_bytes": algorithmic_bytes(nq, nd)},
             "parity_checked": verified,
         }
@@ -216,6 +221,7 @@ def main() -> None:
             state.clear()
             torch.cuda.empty_cache()
             line["secondary"] = secondary_configs(dev)
+            line["secondary"]["ingest"] = ingest_rates(dev)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(64, 100_000, threads)
@@ -245,6 +251,56 @@ def one_query_regime(q1, shard, nd: int, dev) -> dict:
     ach = nbytes / (ms * 1e-3) / 1e9
     return {"workload": f"ands: 1 query x {nd} rows", "value": nd / (ms * 1e-3), "unit": "pair-ops/s",
             "ms": ms, "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+
+
+def ingest_rates(dev) -> dict:
+    """Getting a database into HBM (never part of `value`): packing 1 Mi std::vector rows into host CSR through the
+    C++ front end and uploading it, timed by the small binary built beside the library (rows with the memory layout
+    of the reference's default SDR), and the upload of the same CSR through the C ABI as this process sees it --
+    each next to a plain copy of the same bytes from page-locked memory measured in the same run."""
+    import subprocess
+
+    import torch
+
+    import sdr_amd
+    from sdr_amd import SDRBatch
+    out = {}
+    exe = os.path.join(ROOT, "sdr_amd", "bench_ingest")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe, str(1 << 20), str(WIDTH), str(ACTIVE), "5"], capture_output=True, text=True, timeout=240)
+            out["cpp_front_end"] = json.loads(r.stdout) if r.returncode == 0 else {"error": r.stderr[-300:]}
+        except Exception as e:      # noqa: BLE001 -- the bench line still goes out
+            out["cpp_front_end"] = {"error": repr(e)}
+    else:
+        out["cpp_front_end"] = {"error": "sdr_amd/bench_ingest has not been built"}
+    nd = 1 << 20
+    for name, with_data in (("empty", False), ("unit", True)):
+        off, ids, data = sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE, with_data)
+        nbytes = ids.nbytes * (2 if with_data else 1) + (nd + 1) * 4
+        b = SDRBatch(int(str(dev).split(":")[1]), WIDTH, "unit" if with_data else "empty")
+        b.upload(off, ids, data)
+        best = 1e30
+        for _ in range(5):
+            t0 = time.perf_counter()
+            b.upload(off, ids, data)        # checks included; synchronises
+            best = min(best, time.perf_counter() - t0)
+        pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        target = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        best_pin = 1e30
+        for _ in range(5):
+            t0 = time.perf_counter()
+            target.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
+            best_pin = min(best_pin, time.perf_counter() - t0)
+        out[f"upload_{name}"] = {"workload": f"sdrb_batch_upload_csr: {nd} rows, width {WIDTH}/{ACTIVE}, "
+                                             f"{'UnitData' if with_data else 'EmptyData'} host CSR (pageable numpy arrays)",
+                                 "bytes": int(nbytes), "upload_ms": best * 1e3, "upload_GBps": nbytes / best / 1e9,
+                                 "pinned_h2d_ms": best_pin * 1e3, "pinned_h2d_GBps": nbytes / best_pin / 1e9,
+                                 "upload_vs_pinned": best_pin / best}
+        del b, pinned, target
+    return out
 
 
 I8_PEAK_OPS = 5.03e15   # dense int8 MFMA: 256 CUs x 4 SIMDs x 2048 ops/clk x 2.4 GHz
@@ -391,6 +447,20 @@ def secondary_configs(dev) -> dict:
         return off, ids, np.concatenate([vals[int(csr[0][r]):int(csr[0][r + 1])] for r in rows])
 
     out_buf = torch.empty((nq, nd), dtype=torch.int32, device=dev)
+    # the headline shape with narrow counts (every count is at most 40 / 80 here): the count matrix is the traffic
+    d_csr = sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE)
+    q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE)
+    d, q = SDRBatch.from_csr(*d_csr, width=WIDTH), SDRBatch.from_csr(*q_csr, width=WIDTH)
+    sub_q, sub_d = oracle.Batch(*_gather_rows(q_csr[0], q_csr[1], qi)), oracle.Batch(*_gather_rows(d_csr[0], d_csr[1], dj))
+    for name, op, dtype, nb_out in (("ands", oracle.AND, torch.uint8, 1), ("xors", oracle.XOR, torch.uint8, 1), ("ors", oracle.OR, torch.int16, 2)):
+        narrow_buf = out_buf.view(dtype)[:, : nd]          # rows stay 4 * nd bytes apart: the leading dimension is the caller's
+        ms, _ = _timed(lambda: getattr(q, name)(d, out=narrow_buf, dtype=dtype), reps=5)
+        want = oracle.port().size_op(op, sub_q, sub_d)
+        got = narrow_buf[torch.as_tensor(qi, device=dev)][:, torch.as_tensor(dj, device=dev)].cpu().numpy()
+        got = got.astype(np.uint32) if nb_out == 1 else got.view(np.uint16).astype(np.uint32)
+        out[f"{name}_u{8 * nb_out}"] = line(ms, (nd + nq) * (4 * ACTIVE + 4) + nq * nd * nb_out, bool(np.array_equal(got, want)),
+                                            workload=f"{name}: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData, uint{8 * nb_out} counts[Q][N]")
+    del d, q
     d_csr = sdr_amd.synth_csr(1, 0, nd, WIDTH, ACTIVE, True)
     q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE, True)
     d, q = SDRBatch.from_csr(*d_csr, width=WIDTH), SDRBatch.from_csr(*q_csr, width=WIDTH)

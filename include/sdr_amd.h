@@ -198,6 +198,20 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
                  uint32_t* out, uint64_t ld_out, void* stream);
 
 /*
+ * The same size operations with NARROW counts: out[i*ld_out + j] as uint8 (out_bytes 1) or uint16 (out_bytes 2).
+ * The reference returns size_t (SDR.hpp:31,1085); every value here is bounded by the longest rows -- min(|A_i|, |B_j|)
+ * for ands, |this| for rms, |A_i| + |B_j| for ors and xors -- and at 4096 x 1 Mi pairs the count matrix IS the
+ * memory traffic, so a consumer that thresholds or ranks counts of at most 40 reads and writes a quarter of the bytes.
+ * Served by the bit-sliced kernel only: sizes that depend on ids alone (`this` EmptyData, or SDRB_OP_OR), 32-bit ids,
+ * b with a declared width <= 4096 and rows of at most 64 ids; SDRB_ERR_UNSUPPORTED otherwise, and also when the
+ * bound above does not fit out_bytes (nothing is ever truncated).  out must be 4-byte aligned, ld_out a multiple of
+ * 4 and >= the rows of b; the padding columns of a row up to the next multiple of 4 may be written.
+ * Flags: SDRB_FLAG_SWAP.
+ */
+int sdrb_size_op_narrow(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, void* out, uint64_t ld_out,
+                        int out_bytes, void* stream);
+
+/*
  * sdrb_size_op for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same results, same output
  * layout and the same kernels as sdrb_size_op's bit-sliced path, but the bit table of A lives in a static

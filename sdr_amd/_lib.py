@@ -72,6 +72,7 @@ PROTOTYPES = {
     "sdrb_file_read_rows": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     "sdrb_batch_upload_file": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_uint64, _vp]),
     "sdrb_size_op": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
+    "sdrb_size_op_narrow": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, C.c_int, _vp]),
     "sdrb_size_op_static": (C.c_int, [_vp, _vp, C.c_int, C.c_uint, _vp, C.c_uint64, _vp]),
     "sdrb_range_size": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp]),
     "sdrb_range_elems_count": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _u64p, _vp]),

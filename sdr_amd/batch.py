@@ -395,8 +395,27 @@ class SDRBatch:
                              "'lanemerge', 'lanerank', 'lanerows' or 'masktable'")
         return f
 
-    def _size_op(self, op: int, other: "SDRBatch", swap: bool, out, stream, algo):
+    def _size_op_narrow(self, op: int, other: "SDRBatch", swap: bool, out, stream, dtype):
+        """Counts as uint8 / int16 (uint16 values): the bit-sliced kernel only; refused when a count might not fit."""
         torch = _torch()
+        nbytes = {torch.uint8: 1, torch.int16: 2}.get(dtype)
+        if nbytes is None:
+            raise ValueError("dtype must be torch.int32 (default), torch.uint8 or torch.int16 (uint16 values)")
+        ld = (other.n_rows + 3) // 4 * 4
+        if out is None:
+            out = torch.empty((max(self.n_rows, 1), max(ld, 4)), dtype=dtype, device=f"cuda:{other.device}")
+        if out.dtype != dtype or out.dim() != 2 or out.shape[0] < self.n_rows or out.stride(1) != 1 or out.stride(0) < other.n_rows:
+            raise ValueError("out must be a [>=na, >=nb] tensor of the requested dtype with unit inner stride")
+        check(self._lib.sdrb_size_op_narrow(self._h, other._h, op, FLAG_SWAP if swap else 0, out.data_ptr(), out.stride(0),
+                                            nbytes, _stream_handle(other.device, stream)))
+        return out[: self.n_rows, : other.n_rows]
+
+    def _size_op(self, op: int, other: "SDRBatch", swap: bool, out, stream, algo, dtype=None):
+        torch = _torch()
+        if dtype is not None and dtype != torch.int32:
+            if algo not in (None, "bitslice"):
+                raise ValueError("narrow counts come from the bit-sliced kernel only")
+            return self._size_op_narrow(op, other, swap, out, stream, dtype)
         if out is None:
             out = torch.empty((self.n_rows, other.n_rows), dtype=torch.int32,
                               device=f"cuda:{other.device}")
@@ -493,18 +512,20 @@ class SDRBatch:
                                            rows.data_ptr(), _stream_handle(other.device, stream)))
         return counts, rows
 
-    def ands(self, other, *, swap=False, out=None, stream=None, algo=None):
-        """``out[i, j] = self[i].ands(other[j])`` (uint32 counts in an int32 tensor)."""
-        return self._size_op(OP_AND, other, swap, out, stream, algo)
+    def ands(self, other, *, swap=False, out=None, stream=None, algo=None, dtype=None):
+        """``out[i, j] = self[i].ands(other[j])`` (uint32 counts in an int32 tensor).  ``dtype=torch.uint8`` /
+        ``torch.int16`` asks for narrow counts (a view of a row-padded tensor): every count is bounded by the
+        longest rows, and the call is refused rather than truncating when the bound does not fit."""
+        return self._size_op(OP_AND, other, swap, out, stream, algo, dtype)
 
-    def ors(self, other, *, swap=False, out=None, stream=None, algo=None):
-        return self._size_op(OP_OR, other, swap, out, stream, algo)
+    def ors(self, other, *, swap=False, out=None, stream=None, algo=None, dtype=None):
+        return self._size_op(OP_OR, other, swap, out, stream, algo, dtype)
 
-    def xors(self, other, *, swap=False, out=None, stream=None, algo=None):
-        return self._size_op(OP_XOR, other, swap, out, stream, algo)
+    def xors(self, other, *, swap=False, out=None, stream=None, algo=None, dtype=None):
+        return self._size_op(OP_XOR, other, swap, out, stream, algo, dtype)
 
-    def rms(self, other, *, swap=False, out=None, stream=None, algo=None):
-        return self._size_op(OP_RM, other, swap, out, stream, algo)
+    def rms(self, other, *, swap=False, out=None, stream=None, algo=None, dtype=None):
+        return self._size_op(OP_RM, other, swap, out, stream, algo, dtype)
 
     # -- element ops (SDR.hpp:151-152, 209-212, 237-240, 292-293) ---------------------
     SINGLE_CALL_BYTES = 24 << 30    # largest bound-sized result buffer the single-call path allocates

@@ -636,6 +636,58 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     return launch_size_merge(a, b, op, swap, out, ld_out, false, s);
 }
 
+int sdrb_size_op_narrow(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, void* out, uint64_t ld_out,
+                        int out_bytes, void* stream) {
+    TraceRange range("sdrb_size_op_narrow");
+    narrow_pair(a, b, flags);
+    int rc = check_pair(a, b, op);
+    if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_size_op_narrow");
+    if (rc != SDRB_OK) return rc;
+    if (out_bytes != 1 && out_bytes != 2) {
+        set_error("sdrb_size_op_narrow: out_bytes must be 1 (uint8 counts) or 2 (uint16 counts)");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (flags & ~(SDRB_FLAG_SWAP | SDRB_FLAG_FORCE_BITSLICE)) {
+        set_error("sdrb_size_op_narrow takes SDRB_FLAG_SWAP (and SDRB_FLAG_FORCE_BITSLICE, which it implies) only");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    const bool swap = (flags & SDRB_FLAG_SWAP) != 0;
+    if (a->data_kind == SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_ARITH) {
+        // ArithData payloads are always relevant: ands and ors are those of the id sets, an EmptyData `this` is ids only
+        const sdrb_batch* self = swap ? b : a;
+        if (op == SDRB_OP_XOR || (op == SDRB_OP_RM && self->data_kind == SDRB_DATA_ARITH)) {
+            set_error("sdrb_size_op_narrow: this op on ArithData batches is served by sdrb_size_op only");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        IdView va(a), vb(b);
+        return sdrb_size_op_narrow(&va.v, &vb.v, op, flags, out, ld_out, out_bytes, stream);
+    }
+    if (!id_only(a, b, op, swap) || !bitslice_applicable(a, b)) {
+        set_error("sdrb_size_op_narrow serves the bit-sliced kernel only: sizes that depend on ids alone (`this` "
+                  "EmptyData, or ors), b with a declared width <= 4096 and rows <= 64 ids");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    const uint64_t bound = size_op_bound(a, b, op, swap), most = out_bytes == 1 ? 0xFFu : 0xFFFFu;
+    if (bound > most) {
+        set_error("sdrb_size_op_narrow: a result may reach %llu, more than %d byte(s) hold (the longest rows have %u and "
+                  "%u ids)", (unsigned long long)bound, out_bytes, a->max_row_len, b->max_row_len);
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
+    if (!out || ld_out < b->n_rows || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 3u) != 0 ||
+        ld_out * (uint64_t)out_bytes > (1ull << 27)) {
+        set_error("sdrb_size_op_narrow: out must be 4-byte aligned, ld_out (%llu) a multiple of 4, >= the rows of b (%llu) "
+                  "and at most 2^27 bytes a row", (unsigned long long)ld_out, (unsigned long long)b->n_rows);
+        return SDRB_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(b->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", b->device);
+        return SDRB_ERR_HIP;
+    }
+    return launch_size_bitslice_narrow(a, b, op, swap, out, out_bytes, ld_out, static_cast<hipStream_t>(stream));
+}
+
 int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                         uint64_t ld_out, void* stream) {
     TraceRange range("sdrb_size_op_static");

@@ -159,6 +159,12 @@ bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b);
 int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                          uint32_t* out, uint64_t ld_out, hipStream_t stream);
 
+// The same kernel writing counts as bytes (out_bytes 1) or 16-bit words (2): out[i * ld_out + j], ld_out a multiple of 4.
+// size_op_bound: the largest value the op can yield for these batches (from the longest rows).
+uint64_t size_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap);
+int launch_size_bitslice_narrow(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, void* out, int out_bytes,
+                                uint64_t ld_out, hipStream_t stream);
+
 // The same kernels with the bit table in a file-scope __device__ array instead of the growing workspace
 // (no hipMalloc anywhere on the path); static_scratch_resolve looks the array's address up once per device,
 // with that device current.

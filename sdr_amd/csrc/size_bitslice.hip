@@ -36,10 +36,26 @@ void* g_static_ptr[kMaxDevices];   // device address of `scratch` on each device
 // One tile: gather the row's table words from LDS buffer `buf`, count, unpack, store.
 // `rows_in_tile` < 64 only for the last tile of A; stores to the missing rows are switched
 // off by a zero-sized buffer descriptor, lanes past the last row of B by `nrec`.
-template <int NCH, int MODE>
+//
+// OUTB = 4: a lane stores the uint32 count of its row of B for one row of A per instruction (256 B per wave and row).
+// OUTB = 1 / 2 (counts as bytes / 16-bit words): the four lanes of a quad first exchange their registers -- a 4 x 4
+// byte transpose in two steps of a DPP move and a byte permute -- so that a lane holds the counts of ONE row of A for
+// the quad's four neighbouring rows of B and stores them as one dword (two for 16-bit counts): a wave instruction
+// then writes 64 (128) contiguous bytes to each of four rows of A, a quarter of the store instructions for a quarter
+// (half) of the bytes.  `narrow` carries what the narrow forms need per lane (see NarrowLane).
+struct NarrowLane {
+    uint32_t sel_a, sel_b;     // byte selectors of the two transpose steps for this lane of its quad
+    uint32_t row_in_quad;      // lane & 3: which of the four rows r, r+8, r+16, r+24 the lane stores
+    uint32_t lb_lo, lb_hi;     // |B_j| of the quad's four rows of B, packed as bytes (lb_lo) or 16-bit pairs (lb_lo, lb_hi)
+    uint32_t voff;             // byte offset of the lane's store inside a row group: row_in_quad * 8 rows + its columns
+    bool cols_ok;              // the quad's rows of B exist
+};
+
+template <int NCH, int MODE, int OUTB>
 __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[8 * NCH],
                                           uint32_t rows_in_tile, uint32_t la_vec, uint32_t lbterm,
-                                          char* tile_out, uint64_t row_bytes, uint32_t nrec, uint32_t voff) {
+                                          char* tile_out, uint64_t row_bytes, uint32_t nrec, uint32_t voff,
+                                          const NarrowLane& narrow) {
     constexpr int NPL = bits_for(8 * NCH);
     constexpr int SH = MODE == 2 ? 1 : 0;
     const char* base = reinterpret_cast<const char*>(buf);
@@ -79,6 +95,39 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
             }
             acc[r] = a;
         }
+        if constexpr (OUTB != 4) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                // transpose inside the quad: afterwards this lane holds row (32 h + r + 8 * row_in_quad) of A for the
+                // quad's four rows of B, one count per byte
+                const uint32_t x = acc[r];
+                const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                const uint32_t t = __builtin_amdgcn_perm(y, x, narrow.sel_a);
+                const uint32_t z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, false);   // lane ^ 2
+                uint32_t u = __builtin_amdgcn_perm(z, t, narrow.sel_b);
+                const uint32_t q = 32u * h + r + 8u * narrow.row_in_quad;
+                uint32_t la = 0;
+                if constexpr (MODE != 0) la = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q * 4u), (int)la_vec);
+                char* group = row_ptr + (uint64_t)r * row_bytes;
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(group, 0, (int)0xFFFFFFFFu, 0x00020000);
+                const bool live = narrow.cols_ok && q < rows_in_tile;
+                if constexpr (OUTB == 1) {
+                    if constexpr (MODE != 0) u = la * 0x01010101u + narrow.lb_lo - u;
+                    if (live) __builtin_amdgcn_raw_buffer_store_b32(u, rsrc, (int)narrow.voff, 0, 0);
+                } else {
+                    uint32_t lo2 = (u & 0xffu) | ((u & 0xff00u) << 8), hi2 = ((u >> 16) & 0xffu) | ((u >> 8) & 0xff0000u);
+                    if constexpr (MODE != 0) {
+                        lo2 = la * 0x00010001u + narrow.lb_lo - lo2;
+                        hi2 = la * 0x00010001u + narrow.lb_hi - hi2;
+                    }
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 both = {lo2, hi2};
+                    if (live) __builtin_amdgcn_raw_buffer_store_b64(both, rsrc, (int)narrow.voff, 0, 0);
+                }
+            }
+            row_ptr += 32 * row_bytes;
+            continue;
+        }
 #pragma unroll
         for (int qq = 0; qq < 32; ++qq) {
             const int q = 32 * h + qq;
@@ -100,12 +149,13 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
 // MODE : 0 -> out = m;  1 -> out = L - m;  2 -> out = L - 2m   (m = id matches,
 //        L = use_la*|A_i| + use_lb*|B_j|)
 // WCAP : table words per tile; one tile fills one LDS buffer, two buffers alternate
-template <int NCH, int MODE, int WCAP>
+// OUTB : bytes per count in `out` (4: uint32, the reference's size_t narrowed; 1 / 2: see tile_body)
+template <int NCH, int MODE, int WCAP, int OUTB>
 __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_bitslice(
     const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb,
     const u64* __restrict__ table, const uint32_t* __restrict__ a_len, uint32_t ntiles,
     uint32_t tiles_per_block, uint32_t na, uint32_t use_la, uint32_t use_lb,
-    uint32_t* __restrict__ out, uint64_t ld_out) {
+    void* __restrict__ out, uint64_t ld_out) {
     constexpr int NPL = bits_for(8 * NCH);
     static_assert(NPL + (MODE == 2 ? 1 : 0) <= 8, "counts must fit one byte during unpacking");
     constexpr int BUF = WCAP + 2;          // words per LDS buffer (zero sentinel at [WCAP])
@@ -159,11 +209,29 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_b
     write_tile(pf, lds, tid);
     __syncthreads();
 
-    const uint64_t row_bytes = ld_out * 4;
+    const uint64_t row_bytes = ld_out * OUTB;
     const uint64_t rows_here = nb - j0 < (uint64_t)kBlock ? nb - j0 : (uint64_t)kBlock;
     const uint32_t nrec = (uint32_t)rows_here * 4;
     const uint32_t voff = tid * 4;
-    char* const out_block = reinterpret_cast<char*>(out) + j0 * 4;
+    char* const out_block = reinterpret_cast<char*>(out) + j0 * OUTB;
+    NarrowLane narrow{};
+    if constexpr (OUTB != 4) {
+        narrow.sel_a = (tid & 1) ? 0x03070105u : 0x06020400u;
+        narrow.sel_b = (tid & 2) ? 0x03020706u : 0x05040100u;
+        narrow.row_in_quad = tid & 3;
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lbterm, 0x00, 0xf, 0xf, false);
+        const uint32_t l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lbterm, 0x55, 0xf, 0xf, false);
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lbterm, 0xAA, 0xf, 0xf, false);
+        const uint32_t l3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lbterm, 0xFF, 0xf, 0xf, false);
+        if constexpr (OUTB == 1) {
+            narrow.lb_lo = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
+        } else {
+            narrow.lb_lo = l0 | (l1 << 16);
+            narrow.lb_hi = l2 | (l3 << 16);
+        }
+        narrow.voff = (uint32_t)((tid & 3) * 8u * row_bytes) + (tid & ~3u) * OUTB;
+        narrow.cols_ok = (uint64_t)(tid & ~3u) < rows_here;
+    }
 
     for (uint32_t t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
@@ -177,10 +245,10 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_b
         const uint32_t rows_in_tile = rows_left < (uint32_t)kTileRows ? rows_left : (uint32_t)kTileRows;
         // one straight-line body per LDS buffer so that LDS addresses fold into instruction offsets
         if (((t - t0) & 1) == 0) {
-            tile_body<NCH, MODE>(lds, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff);
+            tile_body<NCH, MODE, OUTB>(lds, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff, narrow);
             if (more) write_tile(pf, lds + BUF, tid);
         } else {
-            tile_body<NCH, MODE>(lds + BUF, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff);
+            tile_body<NCH, MODE, OUTB>(lds + BUF, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff, narrow);
             if (more) write_tile(pf, lds, tid);
         }
         __syncthreads();
@@ -279,22 +347,30 @@ struct Args {
     const uint32_t* a_len;
     uint32_t ntiles, tiles_per_block, use_la, use_lb;
     dim3 grid;
-    uint32_t* out;
+    void* out;
+    int out_bytes;
     uint64_t ld_out;
     hipStream_t stream;
 };
 
-template <int NCH, int MODE, int WCAP>
+template <int NCH, int MODE, int WCAP, int OUTB>
 void launch(const Args& g) {
-    hipLaunchKernelGGL((k_size_bitslice<NCH, MODE, WCAP>), g.grid, dim3(kBlock), 0, g.stream,
+    hipLaunchKernelGGL((k_size_bitslice<NCH, MODE, WCAP, OUTB>), g.grid, dim3(kBlock), 0, g.stream,
                        g.b->d_offsets, g.b->d_ids, g.b->n_rows, g.table, g.a_len, g.ntiles,
                        g.tiles_per_block, (uint32_t)g.a->n_rows, g.use_la, g.use_lb, g.out, g.ld_out);
 }
 
+template <int NCH, int MODE, int WCAP>
+void launch_o(const Args& g) {
+    if (g.out_bytes == 1) launch<NCH, MODE, WCAP, 1>(g);
+    else if (g.out_bytes == 2) launch<NCH, MODE, WCAP, 2>(g);
+    else launch<NCH, MODE, WCAP, 4>(g);
+}
+
 template <int NCH, int MODE>
 void launch_w(const Args& g, int wcap) {
-    if (wcap == 2048) launch<NCH, MODE, 2048>(g);
-    else launch<NCH, MODE, 4096>(g);
+    if (wcap == 2048) launch_o<NCH, MODE, 2048>(g);
+    else launch_o<NCH, MODE, 4096>(g);
 }
 
 template <int MODE>
@@ -316,8 +392,9 @@ bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b) {
 
 namespace {
 // ws_fixed: caller-provided scratch of ws_fixed_bytes (the static array); null: the growing workspace
-int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
+int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, void* out_any, int out_bytes,
                             uint64_t ld_out, hipStream_t stream, char* ws_fixed, size_t ws_fixed_bytes) {
+    uint32_t* out = static_cast<uint32_t*>(out_any);
     Plan plan;
     if (!make_plan(a, b, &plan)) {
         set_error("bit-sliced size kernel not applicable (needs 0 < width <= 4096 and rows <= 64 ids on the streamed batch)");
@@ -325,7 +402,7 @@ int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bo
     }
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;
 
-    if (a->n_rows <= kFewRows) {
+    if (a->n_rows <= kFewRows && out_bytes == 4) {
         const uint32_t quads = (b->max_row_len + 3) / 4;   // <= 16: rows of B hold at most 64 ids here
         const uint64_t pieces = ((uint64_t)b->n_rows + kBlock - 1) / kBlock;
         const uint32_t grid = (uint32_t)(pieces < 2048 ? pieces : 2048);   // eight blocks per compute unit
@@ -390,7 +467,8 @@ int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bo
     g.tiles_per_block = (g.ntiles + gy - 1) / gy;
     gy = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
     g.grid = dim3(gx, gy);
-    g.out = out;
+    g.out = out_any;
+    g.out_bytes = out_bytes;
     g.ld_out = ld_out;
     g.stream = stream;
 
@@ -423,7 +501,20 @@ int launch_size_bitslice_ws(const sdrb_batch* a, const sdrb_batch* b, int op, bo
 
 int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                          uint32_t* out, uint64_t ld_out, hipStream_t stream) {
-    return launch_size_bitslice_ws(a, b, op, swap, out, ld_out, stream, nullptr, 0);
+    return launch_size_bitslice_ws(a, b, op, swap, out, 4, ld_out, stream, nullptr, 0);
+}
+
+// The largest value `op` can yield for any pair of these batches, from the longest rows alone.
+uint64_t size_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
+    const uint64_t la = a->max_row_len, lb = b->max_row_len;
+    if (op == SDRB_OP_AND) return la < lb ? la : lb;
+    if (op == SDRB_OP_RM) return swap ? lb : la;
+    return la + lb;
+}
+
+int launch_size_bitslice_narrow(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, void* out, int out_bytes,
+                                uint64_t ld_out, hipStream_t stream) {
+    return launch_size_bitslice_ws(a, b, op, swap, out, out_bytes, ld_out, stream, nullptr, 0);
 }
 
 // Device address of the static scratch on `device`, which must be the current device.  The first call on a
@@ -448,7 +539,7 @@ int launch_size_bitslice_static(const sdrb_batch* a, const sdrb_batch* b, int op
     void* ptr = nullptr;
     const int rc = static_scratch_resolve(b->device, &ptr);
     if (rc != SDRB_OK) return rc;
-    return launch_size_bitslice_ws(a, b, op, swap, out, ld_out, stream, static_cast<char*>(ptr), kStaticScratchBytes);
+    return launch_size_bitslice_ws(a, b, op, swap, out, 4, ld_out, stream, static_cast<char*>(ptr), kStaticScratchBytes);
 }
 
 }  // namespace sdrb
