@@ -602,6 +602,16 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // Ids no table kernel takes as they are (no declared width, a width beyond every table, 64-bit ids that do not fit
+    // 32 bits): small labels first, then the table kernels on the labelled rows.
+    constexpr unsigned kForced = SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_FORCE_BITSLICE | SDRB_FLAG_FORCE_POPCOUNT | SDRB_FLAG_FORCE_ROWTABLE |
+                                 SDRB_FLAG_FORCE_SPARSE | SDRB_FLAG_FORCE_MASKTABLE;
+    if (!rowwise && !(flags & (kForced | kFlagLabelled))) {
+        const bool direct = a->id_bits == 32 &&
+                            (can_bitslice || (id_only(a, b, op, swap) && popcount_applicable(a, b)) ||
+                             size_lane_rows_applicable(a, b, op, swap, false) || mask_table_applicable(a, b) || unit_table_applicable(a, b));
+        if (!direct && size_relabel_applicable(a, b, op, swap)) return launch_size_relabel(a, b, op, flags, out, ld_out, s);
+    }
     if (rowwise || a->id_bits == 64) return launch_size_merge(a, b, op, swap, out, ld_out, rowwise, s);
     if ((flags & SDRB_FLAG_FORCE_MASKTABLE) && !mask_table_applicable(a, b)) {
         set_error("mask-table kernel requested but not applicable (needs a declared width whose table fits LDS)");

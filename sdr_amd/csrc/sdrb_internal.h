@@ -172,6 +172,15 @@ int static_scratch_resolve(int device, void** ptr);
 int launch_size_bitslice_static(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out,
                                 uint64_t ld_out, hipStream_t stream);
 
+// relabel.hip ---------------------------------------------------------------------
+// Size ops of batches whose ids no table kernel takes as they are (no declared width, a width beyond every table,
+// 64-bit ids): the ids are replaced by small labels, chunk of A by chunk, and the op runs on the labelled views.
+// kFlagLabelled marks the inner calls (never set by callers): such a call does not label again.
+constexpr unsigned kFlagLabelled = 1u << 30;
+bool size_relabel_applicable(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap);
+int launch_size_relabel(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out, uint64_t ld_out,
+                        hipStream_t stream);
+
 // size_merge.hip ------------------------------------------------------------------
 // rowwise: result j = A_j.op(B_j) for two batches of equal length, out[j]
 // (both batches hold ids of the same width: 32 or 64 bits)

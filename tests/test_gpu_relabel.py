@@ -1,0 +1,85 @@
+"""Size operations of batches whose ids no table kernel takes as they are -- no declared width, negative ids, 64-bit ids
+that do not fit 32 bits, widths beyond every table -- go through small labels (relabel.hip) and the table kernels.  Every
+count must equal the oracle's and the per-pair merge kernel's."""
+import numpy as np
+import pytest
+
+import oracle
+import sdr_amd
+import util
+from oracle import AND, OR, RM, XOR, Batch
+from sdr_amd import SDRBatch
+
+pytestmark = pytest.mark.gpu
+
+PAIRINGS = {"EE": (False, False), "UU": (True, True), "UE": (True, False), "EU": (False, True)}
+NAMES = {AND: "ands", OR: "ors", XOR: "xors", RM: "rms"}
+
+
+def sizes(op, t, a, **kw):
+    return getattr(t, NAMES[op])(a, **kw).cpu().numpy().view(np.uint32)
+
+
+def spread(ids, factor, shift):
+    """The same rows with ids far apart and partly negative: order kept."""
+    return ids.astype(np.int64) * factor - shift
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("nt,na,len_t,len_a", [(1, 3000, 40, 40), (70, 1500, 40, 40), (300, 700, 40, 40), (5, 600, 300, 500),
+                                               (130, 400, 64, 64), (9, 300, 2000, 33), (3, 257, 0, 40)])
+def test_widthless_sizes_vs_oracle_and_merge(name, nt, na, len_t, len_a):
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(nt * 7 + na + len_t)
+    width = 5000
+    if len_t:
+        t = Batch(*util.ragged_rows(rng, nt, width, len_t, tu, lo=-2500))
+    else:
+        t = Batch(np.zeros(nt + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if tu else None)
+    a = Batch(*util.ragged_rows(rng, na, width, len_a, au, lo=-2500))
+    dt, da = SDRBatch.from_csr(t.off, t.ids, t.data), SDRBatch.from_csr(a.off, a.ids, a.data)       # no declared width
+    for op in (AND, OR, XOR, RM):
+        for swap in (False, True):
+            want = oracle.port().size_op(op, a, t).T if swap else oracle.port().size_op(op, t, a)
+            assert np.array_equal(sizes(op, dt, da, swap=swap), want), (NAMES[op], swap)
+            assert np.array_equal(sizes(op, dt, da, swap=swap, algo="merge"), want), (NAMES[op], swap, "merge")
+
+
+@pytest.mark.parametrize("name", ["EE", "UU"])
+def test_64_bit_ids_beyond_32_bits_and_huge_declared_widths(name):
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(17)
+    t = Batch(*util.ragged_rows(rng, 150, 3000, 40, tu))
+    a = Batch(*util.ragged_rows(rng, 2000, 3000, 40, au))
+    far_t = SDRBatch.from_csr(t.off, spread(t.ids, 0x100000003, 0x4000000000), t.data)
+    far_a = SDRBatch.from_csr(a.off, spread(a.ids, 0x100000003, 0x4000000000), a.data)
+    wide_t = SDRBatch.from_csr(t.off, t.ids * 300, t.data, width=1_000_000)
+    wide_a = SDRBatch.from_csr(a.off, a.ids * 300, a.data, width=1_000_000)
+    for op in (AND, OR, XOR, RM):
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(sizes(op, far_t, far_a), want), NAMES[op]
+        assert np.array_equal(sizes(op, wide_t, wide_a), want), NAMES[op]
+        assert np.array_equal(sizes(op, far_t, far_a, algo="merge"), want), NAMES[op]
+
+
+def test_config_shaped_widthless_unitdata_rows():
+    """Config 4's shape (16 384 / 328, UnitData) without a declared width: two chunks of A, the mask-table kernel."""
+    w, act = 16384, 328
+    t_csr = sdr_amd.synth_csr(2, 0, 64, w, act, True)
+    a_csr = sdr_amd.synth_csr(1, 0, 1500, w, act, True)
+    t, a = Batch(*t_csr), Batch(*a_csr)
+    dt, da = SDRBatch.from_csr(*t_csr), SDRBatch.from_csr(*a_csr)
+    for op in (AND, XOR, RM):
+        assert np.array_equal(sizes(op, dt, da), oracle.port().size_op(op, t, a)), NAMES[op]
+
+
+def test_element_ops_of_widthless_batches_still_equal_the_oracle():
+    rng = np.random.default_rng(4)
+    t = Batch(*util.ragged_rows(rng, 40, 4000, 40, True, lo=-2000))
+    a = Batch(*util.ragged_rows(rng, 900, 4000, 40, True, lo=-2000))
+    dt, da = SDRBatch.from_csr(t.off, t.ids, t.data), SDRBatch.from_csr(a.off, a.ids, a.data)
+    for op, name in ((AND, "ande"), (OR, "ore"), (XOR, "xore"), (RM, "rme")):
+        off, ids, data = getattr(dt, name)(da).to_host()
+        w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids), name
+        assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), name

@@ -79,6 +79,34 @@ def main():
                 "elem_GBps": round((in_bytes + out_bytes) / ms_e / 1e6, 1),
                 "pair_ops_per_s": round(nq * nd / (ms_e * 1e-3), 0)}), flush=True)
             del res, counts
+    if "widthless" in args.cases:
+        # The same shapes with NO declared width (the reference's ids are arbitrary ints): the per-pair merge kernel
+        # against the default choice (small labels, then the table kernels), and the declared-width time beside them.
+        shapes = [("c2 slab", 64, args.rows, 2048, 40, False, "ands"), ("c3", 16, args.rows, 2048, 40, False, "ands"),
+                  ("c3 one query", 1, args.rows, 2048, 40, False, "ands"), ("c2 512 queries", 512, args.rows, 2048, 40, False, "ands"),
+                  ("c4", 64, args.rows // 8, 16384, 328, True, "ands"), ("c4 ors", 64, args.rows // 8, 16384, 328, True, "ors"),
+                  ("unit 2048/40", 64, args.rows, 2048, 40, True, "ands")]
+        for tag, nq, nd, width, active, unit, sname in shapes:
+            q_csr = sdr_amd.synth_csr(2, 0, nq, width, active, unit)
+            d_csr = sdr_amd.synth_csr(1, 0, nd, width, active, unit)
+            out = torch.empty((nq, nd), dtype=torch.int32, device="cuda:0")
+            times = {}
+            for label, w in (("declared", width), ("widthless", 0)):
+                q, d = SDRBatch.from_csr(*q_csr, width=w), SDRBatch.from_csr(*d_csr, width=w)
+                times[label], _ = timed(lambda: getattr(q, sname)(d, out=out), args.reps)
+                if w == 0:
+                    ref = out.clone()
+                    times["merge"], _ = timed(lambda: getattr(q, sname)(d, out=out, algo="merge"), max(1, args.reps // 2))
+                    same = bool(torch.equal(ref, out))
+                del q, d
+            eb = 8 if unit and sname != "ors" else 4
+            nbytes = (nd + nq) * (eb * active + 4) + nq * nd * 4
+            print(json.dumps({"case": "widthless", "shape": tag, "queries": nq, "rows": nd, "width": width, "active": active,
+                              "unit": unit, "op": sname, "declared_ms": round(times["declared"], 4),
+                              "widthless_ms": round(times["widthless"], 4), "merge_ms": round(times["merge"], 4),
+                              "speedup_over_merge": round(times["merge"] / times["widthless"], 1), "equal": same,
+                              "widthless_GBps": round(nbytes / times["widthless"] / 1e6, 1),
+                              "merge_pair_ops_per_s": round(nq * nd / (times["merge"] * 1e-3), 0)}), flush=True)
     if "inner" in args.cases:
         # sparse dot products (SDR::inner / diff_mul): 4096 x rows pairs at 2048/40 with float payloads,
         # and the matrix x vector shape (1 x rows)
