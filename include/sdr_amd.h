@@ -83,6 +83,7 @@ extern "C" {
                                         (sdrb_inner also takes FORCE_ROWTABLE: the dense value-table kernel, and FORCE_MERGE:
                                         the per-pair merge) */
 #define SDRB_FLAG_FORCE_MASKTABLE 4096u /* size ops: fail with UNSUPPORTED unless the 64-row mask-table kernel applies */
+#define SDRB_FLAG_FORCE_BITSLICE_LONG 8192u /* size ops: fail with UNSUPPORTED unless the bit-sliced kernel for long rows / wide tables applies */
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;

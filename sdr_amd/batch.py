@@ -390,9 +390,11 @@ class SDRBatch:
             f |= _lib.FLAG_FORCE_SPARSE
         elif algo == "masktable":   # size ops by the 64-row mask-table kernel
             f |= _lib.FLAG_FORCE_MASKTABLE
+        elif algo == "bitslice_long":   # id-only size ops by the bit-sliced kernel for long rows / wide tables
+            f |= _lib.FLAG_FORCE_BITSLICE_LONG
         elif algo is not None:
             raise ValueError("algo must be None, 'merge', 'bitslice', 'popcount', 'rowtable', 'rank', 'bitmap', "
-                             "'lanemerge', 'lanerank', 'lanerows' or 'masktable'")
+                             "'lanemerge', 'lanerank', 'lanerows', 'masktable' or 'bitslice_long'")
         return f
 
     def _size_op_narrow(self, op: int, other: "SDRBatch", swap: bool, out, stream, dtype):

@@ -26,7 +26,7 @@ constexpr int kTileRows = 64;  // rows of A per table tile = bits of one table w
 
 // one wave per row, kBuildRows rows per block: launch with ceil(n_rows / kBuildRows) blocks of 64 * kBuildRows threads
 constexpr int kBuildRows = 4;
-__global__ __launch_bounds__(64 * kBuildRows) void k_build_table(const uint32_t* __restrict__ a_off,
+__global__ __launch_bounds__(64 * kBuildRows) __attribute__((unused)) void k_build_table(const uint32_t* __restrict__ a_off,
                                                                   const int32_t* __restrict__ a_ids,
                                                                   uint32_t n_rows, int32_t width, uint32_t tile_words,
                                                                   u64* __restrict__ table,

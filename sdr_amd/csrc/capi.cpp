@@ -605,10 +605,10 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     // Ids no table kernel takes as they are (no declared width, a width beyond every table, 64-bit ids that do not fit
     // 32 bits): small labels first, then the table kernels on the labelled rows.
     constexpr unsigned kForced = SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_FORCE_BITSLICE | SDRB_FLAG_FORCE_POPCOUNT | SDRB_FLAG_FORCE_ROWTABLE |
-                                 SDRB_FLAG_FORCE_SPARSE | SDRB_FLAG_FORCE_MASKTABLE;
+                                 SDRB_FLAG_FORCE_SPARSE | SDRB_FLAG_FORCE_MASKTABLE | SDRB_FLAG_FORCE_BITSLICE_LONG;
     if (!rowwise && !(flags & (kForced | kFlagLabelled))) {
         const bool direct = a->id_bits == 32 &&
-                            (can_bitslice || (id_only(a, b, op, swap) && popcount_applicable(a, b)) ||
+                            (can_bitslice || (id_only(a, b, op, swap) && (popcount_applicable(a, b) || bitslice_long_applicable(a, b))) ||
                              size_lane_rows_applicable(a, b, op, swap, false) || mask_table_applicable(a, b) || unit_table_applicable(a, b));
         if (!direct && size_relabel_applicable(a, b, op, swap)) return launch_size_relabel(a, b, op, flags, out, ld_out, s);
     }
@@ -623,6 +623,14 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
                   "rows of b <= 64 ids, rows of a <= 128 ids)");
         return SDRB_ERR_UNSUPPORTED;
     }
+    if (flags & SDRB_FLAG_FORCE_BITSLICE_LONG) {
+        if (a->id_bits != 32 || !id_only(a, b, op, swap) || !bitslice_long_applicable(a, b)) {
+            set_error("bit-sliced kernel for long rows requested but not applicable (sizes that depend on ids alone, a declared "
+                      "width whose table fits the LDS)");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_size_bitslice_long(a, b, op, swap, out, ld_out, s);
+    }
     if (flags & SDRB_FLAG_FORCE_POPCOUNT) {
         if (a->id_bits != 32 || !id_only(a, b, op, swap) || !popcount_applicable(a, b)) {
             set_error("popcount kernel requested but not applicable to these batches/op");
@@ -632,6 +640,13 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
     }
     if (!(flags & SDRB_FLAG_FORCE_MERGE)) {
         if (can_bitslice) return launch_size_bitslice(a, b, op, swap, out, ld_out, s);
+        // longer rows, wider tables: the same formulation with the row streamed and the tile as wide as the batch
+        // (dense rows of a narrow table stay with the popcount kernel, whose cost does not depend on the row length: at
+        // width 2048 the two meet at rows of about 100 ids -- 64 x 1 Mi rows 0.256 against 0.267 ms; at 300 ids 1.9 against 1.1 ms)
+        const bool dense_rows = popcount_applicable(a, b) && (uint64_t)b->max_row_len * 20 > (uint64_t)b->width;
+        if (!(flags & (SDRB_FLAG_FORCE_ROWTABLE | SDRB_FLAG_FORCE_MASKTABLE)) && !dense_rows && id_only(a, b, op, swap) &&
+            bitslice_long_applicable(a, b))
+            return launch_size_bitslice_long(a, b, op, swap, out, ld_out, s);
         // rows too long for the bit-sliced kernel: the popcount kernel's cost does not depend on row length
         if (id_only(a, b, op, swap) && popcount_applicable(a, b))
             return launch_size_popcount(a, b, op, swap, out, ld_out, s);

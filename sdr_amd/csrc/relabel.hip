@@ -89,8 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_label_b(const Id* __restrict__ b_ids
 uint32_t widest_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
     const sdrb_batch* self = swap ? b : a;
     const bool id_only = op == SDRB_OP_OR || self->data_kind == SDRB_DATA_EMPTY;
-    (void)id_only;
     if (b->max_row_len <= 64) return 4096;   // the bit-sliced kernel (ids alone decide), the lane-per-row kernels (payloads)
+    if (id_only) return 32768;               // the bit-sliced kernel for long rows (its LDS table ends near 40 000 ids)
     return 16384;                            // the mask-table kernel (its LDS table ends near 17 800 ids)
 }
 

@@ -159,6 +159,11 @@ bool bitslice_applicable(const sdrb_batch* a, const sdrb_batch* b);
 int launch_size_bitslice(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap,
                          uint32_t* out, uint64_t ld_out, hipStream_t stream);
 
+// size_bitslice_long.hip: the same formulation for rows of B beyond 64 ids and widths beyond 4096 (to about 40 000)
+bool bitslice_long_applicable(const sdrb_batch* a, const sdrb_batch* b);
+int launch_size_bitslice_long(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, uint32_t* out, uint64_t ld_out,
+                              hipStream_t stream);
+
 // The same kernel writing counts as bytes (out_bytes 1) or 16-bit words (2): out[i * ld_out + j], ld_out a multiple of 4.
 // size_op_bound: the largest value the op can yield for these batches (from the longest rows).
 uint64_t size_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap);
