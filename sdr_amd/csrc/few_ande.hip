@@ -347,7 +347,175 @@ __global__ __launch_bounds__(kBlock) void k_few_ande_fill(
     }
 }
 
+
+// ---- at most eight rows of A of at most 64 ids whose kept matches do not depend on B's payloads (`this` EmptyData: every
+// common id; `this` = A UnitData against EmptyData rows: the common ids whose own payload is relevant) ----
+//
+// A pair's result is then a subset of A_i's elements, and 64 bits say which: the count pass leaves that POSITION MASK
+// beside the byte count (8 bytes a pair), and the fill expands masks against A_i instead of walking B a second time
+// (164 bytes a row at 2048 / 40).  Every block builds its own tables -- a byte per id with a bit per row of A, and the
+// position of each id in each row -- from A's few hundred ids.
+constexpr int kMaskRows = 8;
+
+template <int NCH, bool SELF_A>
+__global__ __launch_bounds__(kBlock) void k_few_masks_count(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val, uint32_t na,
+    const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint32_t nb, uint32_t wcap,
+    unsigned long long* __restrict__ pos_mask, uint8_t* __restrict__ cnt8, uint32_t* __restrict__ group_total, uint32_t n_groups) {
+    // LDS: rows[wcap + 4] bytes (bit q: row q of A holds the id; the word at [wcap] stays zero) |
+    //      pos1[kMaskRows][wcap + 4] bytes: 1 + the position of the id in row q of A, 0 where the row does not hold it |
+    //      wave_part[na][4]
+    extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
+    const uint32_t stride = wcap + 4;
+    uint32_t* rows32 = reinterpret_cast<uint32_t*>(few_lds);
+    unsigned char* rows = few_lds;
+    unsigned char* pos1 = few_lds + stride;
+    uint32_t* wave_part = reinterpret_cast<uint32_t*>(few_lds + stride + (size_t)kMaskRows * stride);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t w = tid; w < (stride + na * stride) / 4; w += kBlock) rows32[w] = 0;
+    __syncthreads();
+    unsigned long long relevant[kMaskRows];   // positions of row q whose own payload is relevant (SELF_A), else all
+#pragma unroll
+    for (int q = 0; q < kMaskRows; ++q) relevant[q] = ~0ull;
+    for (uint32_t q = 0; q < na; ++q) {
+        const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+        if (tid < len) {
+            const uint32_t id = (uint32_t)a_ids[beg + tid];
+            if (id < wcap) {   // ids outside B's table cannot match an id of B
+                atomicOr(&rows32[id >> 2], (1u << q) << (8u * (id & 3u)));
+                pos1[q * stride + id] = (unsigned char)(tid + 1);
+            }
+        }
+        if constexpr (SELF_A) {
+            // a match keeps `this`'s payload (UnitData.hpp:43-46) and stays iff that is relevant (SDR.hpp:1017)
+            const bool ok = lane < len && unit_relevant(a_val[beg + lane]);
+            const unsigned long long keep = __builtin_amdgcn_ballot_w64(ok);
+#pragma unroll
+            for (int r = 0; r < kMaskRows; ++r) relevant[r] = q == (uint32_t)r ? keep : relevant[r];
+        }
+    }
+    __syncthreads();
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t j0 = g * kBlock, j = j0 + tid;
+        uint32_t id[8 * NCH], lb;
+        float unused[8 * NCH];
+        load_row<NCH, false>(b_off, b_ids, nullptr, nb, j0, tid, wcap, id, unused, lb);
+        unsigned long long pm[kMaskRows];
+#pragma unroll
+        for (int q = 0; q < kMaskRows; ++q) pm[q] = 0;
+        if (na <= 2) {
+            // one or two rows of A: no branches -- every id reads its position byte in each row (0: not there)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if ((uint32_t)q < na) {
+#pragma unroll
+                    for (int k = 0; k < 8 * NCH; ++k) {
+                        const uint32_t v = pos1[q * stride + (id[k] >> 2)];
+                        pm[q] |= v ? 1ull << (v - 1u) : 0ull;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                uint32_t m[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = rows[id[ch * 8 + k] >> 2];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t mm = m[k];
+                    while (mm != 0) {
+                        const uint32_t q = (uint32_t)__builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const unsigned long long bit = 1ull << (pos1[q * stride + (id[ch * 8 + k] >> 2)] - 1u);
+#pragma unroll
+                        for (int r = 0; r < kMaskRows; ++r) pm[r] |= q == (uint32_t)r ? bit : 0ull;
+                    }
+                }
+            }
+        }
+        for (uint32_t q = 0; q < na; ++q) {
+            unsigned long long mine = pm[0];
+#pragma unroll
+            for (int r = 1; r < kMaskRows; ++r) mine = q == (uint32_t)r ? pm[r] : mine;
+            unsigned long long rel = relevant[0];
+#pragma unroll
+            for (int r = 1; r < kMaskRows; ++r) rel = q == (uint32_t)r ? relevant[r] : rel;
+            mine &= rel;
+            const uint32_t c = (uint32_t)__builtin_popcountll(mine);
+            if (j < nb) {
+                pos_mask[(uint64_t)q * nb + j] = mine;
+                cnt8[(uint64_t)q * nb + j] = (uint8_t)c;
+            }
+            const uint32_t incl = wave_inclusive_scan(c);
+            if (lane == 63) wave_part[q * kWaves + wave] = incl;
+        }
+        __syncthreads();
+        if (tid < na) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) sum += wave_part[tid * kWaves + w];
+            group_total[(uint64_t)tid * n_groups + g] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// the fill of the same path: offsets from the bytes, elements from the position masks and A's rows (in LDS)
+template <bool DATA>
+__global__ __launch_bounds__(kBlock) void k_few_masks_fill(
+    const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val, uint32_t na, uint32_t nb,
+    const unsigned long long* __restrict__ pos_mask, const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ group_base,
+    uint32_t n_groups, uint32_t* __restrict__ out_offsets, int32_t* __restrict__ out_ids, float* __restrict__ out_data,
+    uint64_t capacity) {
+    __shared__ int32_t row_ids[kMaskRows][64];
+    __shared__ float row_val[kMaskRows][64];
+    __shared__ uint32_t wave_part[kMaskRows][kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t e = tid; e < na * 64u; e += kBlock) {
+        const uint32_t q = e >> 6, k = e & 63u, beg = a_off[q], len = a_off[q + 1] - beg;
+        row_ids[q][k] = k < len ? a_ids[beg + k] : 0;
+        if constexpr (DATA) row_val[q][k] = k < len ? a_val[beg + k] : 0.0f;
+    }
+    __syncthreads();
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t j = g * kBlock + tid;
+        uint32_t excl[kMaskRows];
+        for (uint32_t q = 0; q < na; ++q) {
+            const uint32_t c = j < nb ? (uint32_t)cnt8[(uint64_t)q * nb + j] : 0u;
+            const uint32_t incl = wave_inclusive_scan(c);
+#pragma unroll
+            for (int r = 0; r < kMaskRows; ++r) excl[r] = q == (uint32_t)r ? incl - c : excl[r];
+            if (lane == 63) wave_part[q][wave] = incl;
+        }
+        __syncthreads();
+        for (uint32_t q = 0; q < na; ++q) {
+            uint32_t p = group_base[(uint64_t)q * n_groups + g];
+            for (uint32_t w = 0; w < wave; ++w) p += wave_part[q][w];
+            uint32_t mine = excl[0];
+#pragma unroll
+            for (int r = 1; r < kMaskRows; ++r) mine = q == (uint32_t)r ? excl[r] : mine;
+            p += mine;
+            if (j < nb) {
+                out_offsets[(uint64_t)q * nb + j] = p;
+                unsigned long long m = pos_mask[(uint64_t)q * nb + j];
+                while (m != 0) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if ((uint64_t)p < capacity) {
+                        out_ids[p] = row_ids[q][k];
+                        if constexpr (DATA) out_data[p] = row_val[q][k];
+                    }
+                    ++p;
+                }
+            }
+        }
+        __syncthreads();   // wave_part is rewritten by the next group
+    }
+}
+
 struct FewPlan {
+    bool masks;    // the position-mask path (few rows of A, kept matches independent of B's payloads)
     int wcap, nch, math;
     uint32_t tile_bytes, ntiles, n_groups, grid;
     size_t lds;
@@ -361,6 +529,17 @@ bool make_plan(const sdrb_batch* a, const sdrb_batch* b, bool swap, FewPlan* p) 
     p->math = pick_math(a, b, SDRB_OP_AND, swap);
     p->wcap = b->width <= 2048 ? 2048 : 4096;
     p->nch = b->max_row_len <= 40 ? 5 : 8;
+    p->masks = a->n_rows <= (uint64_t)kMaskRows && a->max_row_len <= 64 && (p->math == kKeepAll || p->math == kSelfA);
+    if (p->masks) {
+        p->tile_bytes = 0;
+        p->ntiles = 1;
+        p->lds = (size_t)(1 + kMaskRows) * (p->wcap + 4) + (size_t)kMaskRows * kWaves * 4u;
+        p->n_groups = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
+        const uint32_t per_cu = (uint32_t)((160u * 1024u) / (p->lds + 512));
+        const uint32_t resident = 256u * (per_cu < 8u ? per_cu : 8u);
+        p->grid = p->n_groups < resident ? p->n_groups : resident;
+        return true;
+    }
     const bool with_vals = p->math == kSelfA || p->math == kMul;
     const uint32_t val_cap = with_vals ? ((uint32_t)kTile * (a->max_row_len ? a->max_row_len : 1u) + 3u) & ~3u : 0u;
     // col[w] addresses a payload by a 16-bit byte offset into the tile: every payload the tile can hold must lie below 64 KiB
@@ -425,6 +604,45 @@ int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_
     if (!make_plan(a, b, swap, &p)) {
         set_error("the fused few-rows ande serves at most 32 rows of a, a declared width <= 4096 and rows of b <= 64 ids");
         return SDRB_ERR_UNSUPPORTED;
+    }
+    if (p.masks) {
+        const uint32_t na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
+        const size_t pairs = (size_t)na * nb;
+        const size_t mask_bytes_all = pairs * sizeof(unsigned long long), cnt_bytes = (pairs + 255) & ~(size_t)255;
+        char* ws = static_cast<char*>(workspace(b->device, stream, 12, mask_bytes_all + cnt_bytes + (size_t)na * p.n_groups * sizeof(uint32_t)));
+        if (!ws) return SDRB_ERR_HIP;
+        unsigned long long* pos_mask = reinterpret_cast<unsigned long long*>(ws);
+        uint8_t* cnt8 = reinterpret_cast<uint8_t*>(ws + mask_bytes_all);
+        uint32_t* group_total = reinterpret_cast<uint32_t*>(ws + mask_bytes_all + cnt_bytes);
+        const bool self_a = p.math == kSelfA;
+#define SDRB_MASKS_COUNT(NCH, SELF)                                                                                      \
+    do {                                                                                                                 \
+        if (p.lds > 64 * 1024)                                                                                           \
+            SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_few_masks_count<NCH, SELF>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                       \
+        hipLaunchKernelGGL((k_few_masks_count<NCH, SELF>), dim3(p.grid), dim3(kBlock), p.lds, stream, a->d_offsets, a->d_ids, \
+                           a->d_data, na, b->d_offsets, b->d_ids, nb, (uint32_t)p.wcap, pos_mask, cnt8, group_total, p.n_groups); \
+    } while (0)
+        if (p.nch == 5) {
+            if (self_a) SDRB_MASKS_COUNT(5, true);
+            else SDRB_MASKS_COUNT(5, false);
+        } else {
+            if (self_a) SDRB_MASKS_COUNT(8, true);
+            else SDRB_MASKS_COUNT(8, false);
+        }
+#undef SDRB_MASKS_COUNT
+        SDRB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, na, p.n_groups, total_dev,
+                           out_offsets + (uint64_t)na * nb);
+        SDRB_HIP(hipGetLastError());
+        if (self_a)
+            hipLaunchKernelGGL((k_few_masks_fill<true>), dim3(p.grid), dim3(kBlock), 0, stream, a->d_offsets, a->d_ids, a->d_data, na,
+                               nb, pos_mask, cnt8, group_total, p.n_groups, out_offsets, out_ids, out_data, capacity);
+        else
+            hipLaunchKernelGGL((k_few_masks_fill<false>), dim3(p.grid), dim3(kBlock), 0, stream, a->d_offsets, a->d_ids, a->d_data, na,
+                               nb, pos_mask, cnt8, group_total, p.n_groups, out_offsets, out_ids, out_data, capacity);
+        SDRB_HIP(hipGetLastError());
+        return SDRB_OK;
     }
     const bool with_vals = p.math == kSelfA || p.math == kMul;
     const unsigned char* tables = nullptr;
