@@ -7,9 +7,13 @@
 // the column's bucket (MatrixUtils.hpp:150-190).  On the device the same regrouping is a STABLE
 // sort of the elements by id: the packed CSR already lists elements by ascending row, so within
 // an id the sorted order is ascending row -- the order the reference's own known answers show
-// (src/test.cpp:517-571).  The sort is rocPRIM's LSD radix sort over the id bits (stable by
-// construction); the kernels here label elements with their rows, count the columns and gather.
-#include <rocprim/device/device_radix_sort.hpp>
+// (src/test.cpp:517-571).  The sort is a least-significant-digit radix sort over the id bits, four bits a pass,
+// stable by construction: a wave owns a contiguous tile of the elements; pass by pass it counts its tile's digits
+// (k_digit_counts), the counts of all (digit, tile) pairs are scanned in digit-major order, and the wave walks its
+// tile again in order, ranking the 64 elements of a turn with one ballot per digit value and sending each element to
+// its digit's next free place (k_digit_scatter).  The other kernels label elements with their rows' positions, count
+// the columns and gather.
+#include <utility>
 
 #include "sdrb_internal.h"
 
@@ -52,6 +56,61 @@ __global__ __launch_bounds__(256) void k_gather_transposed(const uint32_t* __res
     if (dst_data) dst_data[p] = src_data[k];
 }
 
+constexpr int kDigitBits = 4, kDigits = 1 << kDigitBits;
+constexpr uint32_t kSortTile = 4096;   // elements a wave owns
+
+// counts[d * n_tiles + tile] = elements of the tile whose digit (key >> shift) & 15 is d
+__global__ __launch_bounds__(64) void k_digit_counts(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shift,
+                                                     uint32_t n_tiles, uint32_t* __restrict__ counts) {
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    const uint64_t t0 = (uint64_t)tile * kSortTile, t1 = t0 + kSortTile < n ? t0 + kSortTile : n;
+    uint32_t mine[kDigits];
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) mine[d] = 0;
+    for (uint64_t k = t0 + lane; k < t1; k += 64) {
+        const uint32_t digit = (keys[k] >> shift) & (kDigits - 1);
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d) mine[d] += digit == (uint32_t)d ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) {
+        uint32_t v = mine[d];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s, 64);
+        if (lane == 0) counts[(uint64_t)d * n_tiles + tile] = v;
+    }
+}
+
+// starts = the exclusive scan of counts: where the tile's elements of each digit go.  Elements keep their order.
+__global__ __launch_bounds__(64) void k_digit_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      uint64_t n, uint32_t shift, uint32_t n_tiles,
+                                                      const uint32_t* __restrict__ starts, uint32_t* __restrict__ keys_out,
+                                                      uint32_t* __restrict__ vals_out) {
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    const uint64_t t0 = (uint64_t)tile * kSortTile, t1 = t0 + kSortTile < n ? t0 + kSortTile : n;
+    uint32_t next[kDigits];   // uniform over the wave: the next free place of each digit
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) next[d] = starts[(uint64_t)d * n_tiles + tile];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint64_t k0 = t0; k0 < t1; k0 += 64) {
+        const uint64_t k = k0 + lane;
+        const bool live = k < t1;
+        const uint32_t key = live ? keys[k] : 0u, val = live ? vals[k] : 0u;
+        const uint32_t digit = live ? (key >> shift) & (kDigits - 1) : 0xFFFFFFFFu;
+        uint32_t place = 0;
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d) {
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(digit == (uint32_t)d);
+            if (digit == (uint32_t)d) place = next[d] + (uint32_t)__builtin_popcountll(same & below);
+            next[d] += (uint32_t)__builtin_popcountll(same);
+        }
+        if (live) {
+            keys_out[place] = key;
+            vals_out[place] = val;
+        }
+    }
+}
+
 }  // namespace
 
 int launch_transpose(const sdrb_batch* src, uint32_t* dst_off, int32_t* dst_ids, float* dst_data, hipStream_t stream) {
@@ -61,24 +120,34 @@ int launch_transpose(const sdrb_batch* src, uint32_t* dst_off, int32_t* dst_ids,
     if (nnz == 0) return SDRB_OK;
     int bits = 1;
     while ((1ull << bits) < width) ++bits;
-    size_t temp_bytes = 0;
-    SDRB_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, nnz, 0, bits, stream));
+    const uint32_t n_tiles = (uint32_t)((nnz + kSortTile - 1) / kSortTile);
     const size_t arr = (nnz * sizeof(uint32_t) + 255) / 256 * 256;
-    char* ws = static_cast<char*>(workspace(src->device, stream, 8, 4 * arr + temp_bytes));
+    const size_t counts_bytes = ((size_t)kDigits * n_tiles + 1) * sizeof(uint32_t);
+    char* ws = static_cast<char*>(workspace(src->device, stream, 8, 4 * arr + counts_bytes));
     if (!ws) return SDRB_ERR_HIP;
     uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws);
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + arr);
     uint32_t* elem_in = reinterpret_cast<uint32_t*>(ws + 2 * arr);
     uint32_t* elem_out = reinterpret_cast<uint32_t*>(ws + 3 * arr);
-    void* temp = ws + 4 * arr;
+    uint32_t* counts = reinterpret_cast<uint32_t*>(ws + 4 * arr);
     hipLaunchKernelGGL(k_label_elements, dim3((n_rows + 3) / 4), dim3(256), 0, stream, src->d_offsets, src->d_ids,
                        n_rows, keys_in, elem_in, dst_off);
     SDRB_HIP(hipGetLastError());
     // column counts -> column offsets (the extra last entry is zero, so the scan's last value is nnz)
     int rc = launch_exclusive_scan_u32(src->device, dst_off, (uint64_t)width + 1, (uint64_t)width, nullptr, stream);
     if (rc != SDRB_OK) return rc;
-    SDRB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, elem_in, elem_out, nnz, 0, bits, stream));
+    for (int shift = 0; shift < bits; shift += kDigitBits) {
+        hipLaunchKernelGGL(k_digit_counts, dim3(n_tiles), dim3(64), 0, stream, keys_in, nnz, (uint32_t)shift, n_tiles, counts);
+        SDRB_HIP(hipGetLastError());
+        rc = launch_exclusive_scan_u32(src->device, counts, (uint64_t)kDigits * n_tiles + 1, (uint64_t)kDigits * n_tiles, nullptr, stream);
+        if (rc != SDRB_OK) return rc;
+        hipLaunchKernelGGL(k_digit_scatter, dim3(n_tiles), dim3(64), 0, stream, keys_in, elem_in, nnz, (uint32_t)shift, n_tiles, counts,
+                           keys_out, elem_out);
+        SDRB_HIP(hipGetLastError());
+        std::swap(keys_in, keys_out);
+        std::swap(elem_in, elem_out);
+    }
+    elem_out = elem_in;   // the last pass's output
     hipLaunchKernelGGL(k_gather_transposed, dim3((uint32_t)((nnz + 255) / 256)), dim3(256), 0, stream, src->d_offsets,
                        n_rows, src->d_data, elem_out, nnz, dst_ids, has_payload(src) ? dst_data : nullptr);
     SDRB_HIP(hipGetLastError());

@@ -96,6 +96,32 @@ def test_element_ops_one_query_against_full_database(problem):
             assert np.array_equal(got, w_ids[int(w_off[k]):int(w_off[k + 1])]), (ename, r)
 
 
+def test_element_ops_sixteen_queries_against_full_database(problem):
+    """Config 3 at 16 queries x 1 Mi rows (the shape the bench line times): result lengths equal the size ops for every
+    pair, totals are their sums, and the elements of every query against 48 sampled rows equal the oracle's."""
+    import torch
+    q_csr, d_csr, q, d, out = problem
+    nq = 16
+    some = SDRBatch.from_csr(q_csr[0][: nq + 1], q_csr[1][: nq * ACTIVE], width=WIDTH)
+    oq = Batch(q_csr[0][: nq + 1], q_csr[1][: nq * ACTIVE])
+    rows = np.sort(np.random.default_rng(5).choice(ND, 48, replace=False))
+    sub_d = gather_rows(d_csr, rows)
+    for op, (sname, ename) in enumerate((("ands", "ande"), ("ors", "ore"), ("xors", "xore"), ("rms", "rme"))):
+        res = getattr(some, ename)(d)
+        sizes = getattr(some, sname)(d).to(torch.int64)
+        lens = torch.diff(res.offsets.to(torch.int64) & 0xFFFFFFFF).view(nq, ND)
+        assert bool((lens == sizes).all()), ename
+        assert res.total == int(sizes.sum()), ename
+        w_off, w_ids, _ = oracle.port().elem_op(op, oq, sub_d)
+        pair = torch.as_tensor(np.add.outer(np.arange(nq) * ND, rows).reshape(-1), device="cuda")
+        lo = (res.offsets[pair].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+        hi = (res.offsets[pair + 1].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+        assert np.array_equal(hi - lo, np.diff(w_off).astype(np.int64)), ename
+        got = np.concatenate([res.ids_buffer[a:b].cpu().numpy() for a, b in zip(lo, hi)])
+        assert np.array_equal(got, w_ids), ename
+        del res
+
+
 def test_ande_whose_worst_case_bound_exceeds_32_bits(problem):
     """256 queries x 1 Mi rows: pairs x shortest row = 1.07e10 could not be indexed with 32 bits, the
     actual intersections (0.78 ids a pair) can -- the sizes are summed exactly before the scan instead

@@ -115,3 +115,26 @@ def test_transpose_known_answer_and_inverted_index():
     # the inverted index answers a point query for all rows at once
     hits = SDRBatch.from_csr(d_off, d_ids, None, width=2048).point_query([17]).cpu().numpy()[0] >= 0
     assert np.flatnonzero(hits).tolist() == rows[int(off[17]):int(off[18])].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,active,n,with_data", [(2048, 40, 300_000, True), (16384, 328, 9_000, False), (17, 5, 70_000, False),
+                                                      (70_000, 3, 50_000, True)])
+def test_transpose_of_large_batches_is_a_stable_regrouping(width, active, n, with_data):
+    """Many tiles of the radix sort, several digit passes (widths of 5, 11, 14 and 17 bits): within an id the rows come
+    out ascending, with the payloads they had -- compared with numpy's stable sort."""
+    import sdr_amd
+    from sdr_amd import SDRBatch
+    off, ids, data = sdr_amd.synth_csr(3, 0, n, width, active, with_data)
+    b = SDRBatch.from_csr(off, ids, data, width=width)
+    t = b.transpose()
+    wire = t.to_wire().cpu().numpy()
+    t_off = wire[: width + 1].view(np.uint32).astype(np.int64)
+    t_rows = wire[width + 1: width + 1 + t.nnz]
+    order = np.argsort(ids, kind="stable")
+    rows_of = np.repeat(np.arange(n, dtype=np.int32), active)
+    assert np.array_equal(t_off, np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=width))]))
+    assert np.array_equal(t_rows, rows_of[order])
+    if with_data:
+        t_data = wire[width + 1 + t.nnz:].view(np.float32)
+        assert np.array_equal(t_data.view(np.uint32), data[order].view(np.uint32))
