@@ -238,6 +238,30 @@ class Table {
     size_t na_, nb_;
     detail::DeviceBuffer buf_;
 };
+// Sizes of results as uint8_t or uint16_t (sdrb_size_op_narrow): rows of the table are `ld` counts apart, ld the next
+// multiple of four of the number of columns.
+template <typename T>
+class NarrowCounts {
+ public:
+    NarrowCounts(int device, size_t na, size_t nb)
+        : na_(na), nb_(nb), ld_((nb + 3) / 4 * 4), buf_(device, (na * ld_ ? na * ld_ : 4) * sizeof(T)) {}
+    size_t rows() const { return na_; }
+    size_t cols() const { return nb_; }
+    size_t ld() const { return ld_; }
+    T* device_ptr() const { return static_cast<T*>(buf_.ptr); }
+    // counts[i * cols() + j], the padding dropped
+    std::vector<T> to_host(void* stream = nullptr) const {
+        const std::vector<T> padded = buf_.to_host<T>(na_ * ld_, stream);
+        std::vector<T> h(na_ * nb_);
+        for (size_t i = 0; i < na_; ++i) std::copy(padded.begin() + i * ld_, padded.begin() + i * ld_ + nb_, h.begin() + i * nb_);
+        return h;
+    }
+
+ private:
+    size_t na_, nb_, ld_;
+    detail::DeviceBuffer buf_;
+};
+
 using Counts = Table<uint32_t>;     // sizes of results
 using Values = Table<float>;        // dot products
 using Positions = Table<int32_t>;   // positions inside rows, -1 = absent
@@ -513,6 +537,17 @@ class SDRBatch {
     Counts ors(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_OR, db, flags, stream); }
     Counts xors(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_XOR, db, flags, stream); }
     Counts rms(const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const { return size_op(SDRB_OP_RM, db, flags, stream); }
+
+    // The same sizes as uint8_t or uint16_t counts (T): for results that depend on ids alone (`this` EmptyData, or ors)
+    // on rows of at most 64 ids over a declared width of at most 4096; refused -- never truncated -- when the longest
+    // rows allow a value that T cannot hold.  op: SDRB_OP_AND / OR / XOR / RM.
+    template <typename T>
+    NarrowCounts<T> size_op_narrow(int op, const SDRBatch& db, unsigned flags = 0, void* stream = nullptr) const {
+        static_assert(std::is_same_v<T, uint8_t> || std::is_same_v<T, uint16_t>, "narrow counts are uint8_t or uint16_t");
+        NarrowCounts<T> c(db.device_, n_rows_, db.n_rows_);
+        check(sdrb_size_op_narrow(h_, db.h_, op, flags, c.device_ptr(), c.ld(), (int)sizeof(T), stream));
+        return c;
+    }
 
     // out(i, j) = (*this)[i].inner(db[j]) on ArithData<float> rows (SDR.hpp:1682-1692), bit for bit.
     // These are also the entries of diff_mul (SDR.hpp:1886-1923; *this = matrix rows, db = the columns

@@ -499,30 +499,59 @@ __device__ inline unsigned long long block_max(unsigned long long v, unsigned lo
     return a > b ? a : b;
 }
 
-// Every element once, coalesced: descents against the element before, id span, payload range.  A block folds its
-// findings in LDS and touches the shared record once (all blocks update the same few words).
+// Every element once, coalesced, four to a thread (one 16-byte load of ids, one of payloads, and the element before
+// the four): descents against the element before, id span, payload range.  A block folds its findings in LDS and
+// touches the shared record once (all blocks update the same few words).
 template <typename Id>
 __global__ __launch_bounds__(256) void k_check_flat(const Id* __restrict__ ids, const float* __restrict__ data, int data_kind,
                                                     uint64_t nnz, DeviceFindings* __restrict__ f) {
     __shared__ unsigned long long part[4][4];
     unsigned long long descents = 0, bad = 0, lo = ~0ull, hi = 0ull;
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (uint64_t)gridDim.x * 256) {
+    const uint64_t quads = nnz / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = q * 4;
+        Id x[4];
+        if constexpr (sizeof(Id) == 4) {
+            const int4 v = *reinterpret_cast<const int4*>(ids + k);   // hipMalloc'ed arrays: 16-byte aligned at multiples of four
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else {
+            const longlong2 v0 = *reinterpret_cast<const longlong2*>(ids + k), v1 = *reinterpret_cast<const longlong2*>(ids + k + 2);
+            x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y;
+        }
+        Id before = k > 0 ? ids[k - 1] : x[0];
+        if (k > 0) descents += x[0] <= before;
+#pragma unroll
+        for (int u = 1; u < 4; ++u) descents += x[u] <= x[u - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long w = (unsigned long long)(long long)x[u] ^ kBias;
+            lo = w < lo ? w : lo;
+            hi = w > hi ? w : hi;
+        }
+        if (data_kind != SDRB_DATA_EMPTY) {
+            const float4 d = *reinterpret_cast<const float4*>(data + k);
+            bad += payload_bad(d.x, data_kind) + payload_bad(d.y, data_kind) + payload_bad(d.z, data_kind) + payload_bad(d.w, data_kind);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(nnz - quads * 4)) {   // the last one to three elements
+        const uint64_t k = quads * 4 + threadIdx.x;
         const Id x = ids[k];
         if (k > 0) descents += x <= ids[k - 1];
-        const unsigned long long u = (unsigned long long)(long long)x ^ kBias;
-        lo = u < lo ? u : lo;
-        hi = u > hi ? u : hi;
+        const unsigned long long w = (unsigned long long)(long long)x ^ kBias;
+        lo = w < lo ? w : lo;
+        hi = w > hi ? w : hi;
         if (data_kind != SDRB_DATA_EMPTY) bad += payload_bad(data[k], data_kind);
     }
     descents = block_sum(descents, part[0]);
     bad = block_sum(bad, part[1]);
     lo = block_min(lo, part[2]);
     hi = block_max(hi, part[3]);
-    if (threadIdx.x == 0) {
-        if (descents) atomicAdd(&f->descents, descents);
-        if (bad) atomicAdd(&f->bad_payloads, bad);
-        atomicMin(&f->min_id, lo);
-        atomicMax(&f->max_id, hi);
+    if (threadIdx.x == 0) {   // one record a block, folded by k_fold_findings: no two blocks write the same word
+        DeviceFindings* mine = f + 1 + blockIdx.x;
+        mine->descents = descents;
+        mine->bad_payloads = bad;
+        mine->min_id = lo;
+        mine->max_id = hi;
     }
 }
 
@@ -545,9 +574,50 @@ __global__ __launch_bounds__(256) void k_check_rows(const uint32_t* __restrict__
     bad_row = block_min(bad_row, part[1]);
     len = block_max(len, part[2]);
     if (threadIdx.x == 0) {
-        if (starts) atomicAdd(&f->at_row_starts, starts);
-        if (bad_row != ~0ull) atomicMin(&f->bad_offset_row, bad_row);
-        atomicMax(&f->max_len, (unsigned int)len);
+        DeviceFindings* mine = f + 1 + blockIdx.x;
+        mine->at_row_starts = starts;
+        mine->bad_offset_row = bad_row;
+        mine->max_len = (unsigned int)len;
+    }
+}
+
+// records that change nothing when folded: sums 0, minima ~0, maxima 0
+__global__ __launch_bounds__(256) void k_neutral_findings(DeviceFindings* __restrict__ f, uint32_t n) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    f[b].bad_offset_row = f[b].min_id = f[b].bad_order_row = f[b].bad_payload_row = ~0ull;
+}
+
+// folds the blocks' records f[1 .. n] into f[0] (one block)
+__global__ __launch_bounds__(256) void k_fold_findings(DeviceFindings* __restrict__ f, uint32_t n) {
+    __shared__ unsigned long long part[7][4];
+    unsigned long long descents = 0, starts = 0, bad = 0, bad_row = ~0ull, lo = ~0ull, hi = 0ull, len = 0;
+    for (uint32_t b = threadIdx.x; b < n; b += 256) {
+        const DeviceFindings& r = f[1 + b];
+        descents += r.descents;
+        starts += r.at_row_starts;
+        bad += r.bad_payloads;
+        bad_row = r.bad_offset_row < bad_row ? r.bad_offset_row : bad_row;
+        lo = r.min_id < lo ? r.min_id : lo;
+        hi = r.max_id > hi ? r.max_id : hi;
+        len = r.max_len > len ? r.max_len : len;
+    }
+    descents = block_sum(descents, part[0]);
+    starts = block_sum(starts, part[1]);
+    bad = block_sum(bad, part[2]);
+    bad_row = block_min(bad_row, part[3]);
+    lo = block_min(lo, part[4]);
+    hi = block_max(hi, part[5]);
+    len = block_max(len, part[6]);
+    if (threadIdx.x == 0) {
+        f->descents = descents;
+        f->at_row_starts = starts;
+        f->bad_payloads = bad;
+        f->bad_offset_row = bad_row;
+        f->min_id = lo;
+        f->max_id = hi;
+        f->max_len = (unsigned int)len;
+        f->bad_order_row = f->bad_payload_row = ~0ull;
     }
 }
 
@@ -572,25 +642,30 @@ __global__ __launch_bounds__(256) void k_locate_findings(const uint32_t* __restr
 template <typename Id>
 int check_on_device(const sdrb_batch* batch, uint64_t n_rows, uint64_t nnz, const uint64_t* off, const Id* ids,
                     const float* data, hipStream_t s, Findings* out) {
-    DeviceFindings* d_f = static_cast<DeviceFindings*>(workspace(batch->device, s, 2, sizeof(DeviceFindings)));
+    // f[0]: the batch's record; f[1 ..]: one record per block of the two kernels (the same blocks' slots serve both:
+    // they write different fields), neutral where a kernel has fewer blocks
+    const uint64_t flat_blocks = nnz ? std::min<uint64_t>(4096, (nnz / 4 + 256 * 4 - 1) / (256 * 4) + 1) : 0;
+    const uint64_t row_blocks = n_rows ? std::min<uint64_t>(4096, (n_rows + 256 * 4 - 1) / (256 * 4)) : 0;
+    const uint32_t slots = (uint32_t)std::max<uint64_t>(std::max(flat_blocks, row_blocks), 1);
+    DeviceFindings* d_f = static_cast<DeviceFindings*>(workspace(batch->device, s, 2, (size_t)(slots + 1) * sizeof(DeviceFindings)));
     if (!d_f) return SDRB_ERR_HIP;
     DeviceFindings f{};
-    f.bad_offset_row = f.min_id = f.bad_order_row = f.bad_payload_row = ~0ull;
-    SDRB_HIP(hipMemcpyAsync(d_f, &f, sizeof f, hipMemcpyHostToDevice, s));
     const Id* d_ids = reinterpret_cast<const Id*>(batch->d_ids);
     const int kind = batch->data_kind;
+    // neutral records: zero sums, ~0 for the minima (0xFF bytes), then the maxima cleared by the kernels that own them
+    SDRB_HIP(hipMemsetAsync(d_f, 0, (size_t)(slots + 1) * sizeof(DeviceFindings), s));
+    hipLaunchKernelGGL(k_neutral_findings, dim3((slots + 1 + 255) / 256), dim3(256), 0, s, d_f, slots + 1);
+    SDRB_HIP(hipGetLastError());
     if (nnz) {
-        const uint64_t blocks = (nnz + 256 * 8 - 1) / (256 * 8);
-        hipLaunchKernelGGL((k_check_flat<Id>), dim3((uint32_t)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, d_ids,
-                           batch->d_data, kind, nnz, d_f);
+        hipLaunchKernelGGL((k_check_flat<Id>), dim3((uint32_t)flat_blocks), dim3(256), 0, s, d_ids, batch->d_data, kind, nnz, d_f);
         SDRB_HIP(hipGetLastError());
     }
     if (n_rows) {
-        const uint64_t blocks = (n_rows + 256 * 4 - 1) / (256 * 4);
-        hipLaunchKernelGGL((k_check_rows<Id>), dim3((uint32_t)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, batch->d_offsets, d_ids,
-                           n_rows, nnz, d_f);
+        hipLaunchKernelGGL((k_check_rows<Id>), dim3((uint32_t)row_blocks), dim3(256), 0, s, batch->d_offsets, d_ids, n_rows, nnz, d_f);
         SDRB_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(k_fold_findings, dim3(1), dim3(256), 0, s, d_f, slots);
+    SDRB_HIP(hipGetLastError());
     SDRB_HIP(hipMemcpyAsync(&f, d_f, sizeof f, hipMemcpyDeviceToHost, s));
     SDRB_HIP(hipStreamSynchronize(s));
     out->max_len = f.max_len;

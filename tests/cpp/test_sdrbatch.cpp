@@ -61,6 +61,17 @@ int run(const char* name, std::mt19937& rng, int width, int32_t declared_width) 
     auto c_and = q.ands(d).to_host(), c_or = q.ors(d).to_host(), c_xor = q.xors(d).to_host(), c_rm = q.rms(d).to_host();
     auto e_and = q.ande(d), e_or = q.ore(d), e_xor = q.xore(d), e_rm = q.rme(d);
     auto h_and = e_and.to_host(), h_or = e_or.to_host(), h_xor = e_xor.to_host(), h_rm = e_rm.to_host();
+    // narrow counts: where the sizes depend on ids alone and the batch declares a width they equal the reference's too
+    constexpr bool ids_decide = !sdr_amd::detail::has_value<typename A::value_type::data_type>::value;
+    if (ids_decide && declared_width > 0 && sizeof(typename A::value_type::id_type) <= 4) {
+        auto n_and = q.template size_op_narrow<uint8_t>(SDRB_OP_AND, d).to_host();
+        auto n_xor = q.template size_op_narrow<uint16_t>(SDRB_OP_XOR, d).to_host();
+        for (size_t i = 0; i < qs.size(); ++i)
+            for (size_t j = 0; j < ds.size(); ++j) {
+                REQUIRE(n_and[i * ds.size() + j] == qs[i].ands(ds[j]));
+                REQUIRE(n_xor[i * ds.size() + j] == qs[i].xors(ds[j]));
+            }
+    }
     // the default result type of the reference is this's element type in a std::vector
     using R = SDR<typename A::value_type, std::vector<typename A::value_type>>;
     for (size_t i = 0; i < qs.size(); ++i)
