@@ -16,5 +16,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIV
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $O/pmc_$name -- $B --steps 3 --warmup 1 --no-verify > $O/pmc_$name.log 2>&1 || { echo "pmc $name failed"; tail -3 $O/pmc_$name.log; exit 1; }
 done
 # calibration of WRITE_SIZE on a known byte count with the same store shape (dword per lane)
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cal_WRITE_SIZE -- $R/tools/exp/lab_store cal > $O/cal_write.log 2>&1 || { echo cal failed; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cal_WRITE_SIZE -- $R/tools/exp/_bin/lab_store cal > $O/cal_write.log 2>&1 || { echo cal failed; exit 1; }
 echo profile done

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_ops_$tag
 mkdir -p $O
-for spec in "c3 1 ande" "c3 16 ande" "c3 1 ore" "c3 16 ore" "c4 64 ande"; do
+for spec in "c3 1 ande" "c3 16 ande" "c3 1 ore" "c3 16 ore" "c4 64 ande" "c3u 1 ande"; do
   set -- $spec
   name=$1_q$2_$3
   P="python3 $R/tools/exp/run_one_op.py $1 $2 $3"

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALLS = 3   # tools/exp/run_one_op.py issues the op three times
-SHAPES = {"c3": (2048, 40, False, 1 << 20), "c4": (16384, 328, True, 1 << 17)}
+SHAPES = {"c3": (2048, 40, False, 1 << 20), "c3u": (2048, 40, True, 1 << 20), "c4": (16384, 328, True, 1 << 17)}
 
 
 def short(name):
@@ -48,7 +48,11 @@ def main():
         algorithmic = (nd + nq) * (eb * active + 4) + (nq * nd + 1) * 4 + (elements or 0) * eb
         stats = glob.glob(os.path.join(case_dir, "kt", "*", "*_kernel_stats.csv"))
         kernels = {}
+        # the kernels of the set-up (the two uploads' checks, the runtime's copies and fills) are not part of a call
+        setup = ("k_check_flat", "k_check_rows", "k_fold_findings", "k_neutral_findings", "k_locate_findings", "__amd_rocclr")
         for r in csv.DictReader(open(stats[0])) if stats else []:
+            if any(x in r["Name"] for x in setup):
+                continue
             kernels[short(r["Name"])] = {"dispatches_per_call": int(r["Calls"]) / CALLS, "avg_ns": float(r["AverageNs"])}
         pmc = {}
         for sub in glob.glob(os.path.join(case_dir, "pmc_*")):
