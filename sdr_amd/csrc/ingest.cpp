@@ -51,15 +51,19 @@ int ensure_stage(int device) {
         set_error("device %d is beyond the staging pool's %d devices", device, kMaxDevices);
         return SDRB_ERR_INVALID_ARG;
     }
-    while (g_stage.size() < kRingSlots) {
-        StageBuffer* sb = new StageBuffer;
-        const hipError_t e = hipHostMalloc(&sb->host, kSlotBytes, hipHostMallocPortable);
+    if (g_stage.empty()) {
+        // one allocation for the whole ring: page-locking memory costs per call as well as per byte
+        void* ring = nullptr;
+        const hipError_t e = hipHostMalloc(&ring, kRingSlots * kSlotBytes, hipHostMallocPortable);
         if (e != hipSuccess) {
-            delete sb;
-            set_error("hipHostMalloc(%zu) for a staging buffer failed: %s", kSlotBytes, hipGetErrorString(e));
+            set_error("hipHostMalloc(%zu) for the staging ring failed: %s", kRingSlots * kSlotBytes, hipGetErrorString(e));
             return SDRB_ERR_HIP;
         }
-        g_stage.push_back(sb);
+        for (size_t k = 0; k < kRingSlots; ++k) {
+            StageBuffer* sb = new StageBuffer;
+            sb->host = static_cast<char*>(ring) + k * kSlotBytes;
+            g_stage.push_back(sb);
+        }
     }
     for (size_t k = 0; k < kRingSlots; ++k)
         if (!g_stage[k]->done[device]) SDRB_HIP(hipEventCreateWithFlags(&g_stage[k]->done[device], hipEventDisableTiming));

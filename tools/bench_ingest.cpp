@@ -96,6 +96,7 @@ static std::vector<RowT> make_rows(uint64_t seed, size_t n, int width, int activ
 }
 
 struct Timing {
+    double first_upload_s = 0;   // the process's first large upload: the staging ring and the copy streams are made here
     double pack_s = 1e30, upload_s = 1e30, pinned_s = 1e30, pageable_s = 1e30;
     uint64_t bytes = 0;
 };
@@ -129,7 +130,10 @@ static Timing measure(const std::vector<RowT>& rows, int width, int repeats) {
         const double t4 = now();
         (void)hipMemcpy(dev, h.ids.get(), h.nnz * 4, hipMemcpyHostToDevice);
         const double t5 = now();
-        if (rep == 0) continue;
+        if (rep == 0) {
+            t.first_upload_s = t2 - t1;
+            continue;
+        }
         t.pack_s = std::min(t.pack_s, t1 - t0);
         t.upload_s = std::min(t.upload_s, t2 - t1);
         t.pinned_s = std::min(t.pinned_s, t4 - t3);
@@ -142,10 +146,10 @@ static Timing measure(const std::vector<RowT>& rows, int width, int repeats) {
 
 static void print(const char* name, const Timing& t, size_t rows, bool last) {
     std::printf("\"%s\": {\"bytes\": %llu, \"pack_ms\": %.3f, \"pack_rows_per_s\": %.4g, \"pack_GBps\": %.2f, "
-                "\"upload_ms\": %.3f, \"upload_GBps\": %.2f, \"pinned_h2d_ms\": %.3f, \"pinned_h2d_GBps\": %.2f, "
+                "\"upload_ms\": %.3f, \"first_upload_ms\": %.3f, \"upload_GBps\": %.2f, \"pinned_h2d_ms\": %.3f, \"pinned_h2d_GBps\": %.2f, "
                 "\"pageable_h2d_GBps\": %.2f, \"upload_vs_pinned\": %.3f, \"rows_per_s_end_to_end\": %.4g}%s",
                 name, (unsigned long long)t.bytes, t.pack_s * 1e3, rows / t.pack_s, t.bytes / t.pack_s / 1e9,
-                t.upload_s * 1e3, t.bytes / t.upload_s / 1e9, t.pinned_s * 1e3, t.bytes / t.pinned_s / 1e9,
+                t.upload_s * 1e3, t.first_upload_s * 1e3, t.bytes / t.upload_s / 1e9, t.pinned_s * 1e3, t.bytes / t.pinned_s / 1e9,
                 t.bytes / t.pageable_s / 1e9, t.pinned_s / t.upload_s, rows / (t.pack_s + t.upload_s), last ? "" : ", ");
 }
 
