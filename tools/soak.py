@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak run on the GPU: random shapes, payload kinds, ops and orientations through the default kernel
 choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids, dot products, the row-wise forms,
-range and point queries -- every result
-compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big|algos]
+range and point queries, narrow counts, ids without a usable width -- every
+result compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big|algos|long]
 Prints a line per 50 cases and a summary; exits non-zero on the first mismatch (the failing case is printed so that
 it can be replayed from its seed)."""
 import os
@@ -27,7 +27,8 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
-    algos = len(sys.argv) > 3 and sys.argv[3] == "algos"
+    algos = len(sys.argv) > 3 and sys.argv[3] in ("algos", "long")
+    long_rows = len(sys.argv) > 3 and sys.argv[3] == "long"
     t_end = time.time() + budget
     case = 0
     checks = 0
@@ -43,8 +44,16 @@ def main():
             declared = width
             na = int(rng.choice([33, 64, 65, 130]))
             nb = int(rng.choice([1025, 2500, 4000]))
+        if long_rows:   # rows beyond one id per lane slot: the streamed bit-sliced kernel and its neighbours
+            width = int(rng.choice([2048, 4096, 16384, 20000, 32768, 39000]))
+            declared = width
+            na = int(rng.choice([1, 7, 64, 65, 100]))
+            nb = int(rng.choice([63, 257, 700, 1500]))
         len_a = int(min(width, rng.choice([0, 1, 5, 20, 40, 41, 64, 65, 128, 129, 300])))
         len_b = int(min(width, rng.choice([0, 1, 5, 20, 40, 41, 64, 65, 128, 300])))
+        if long_rows:
+            len_a = int(rng.choice([40, 328, 1000]))
+            len_b = int(rng.choice([65, 100, 328, 600, 1500]))
         tu, au = bool(rng.integers(2)), bool(rng.integers(2))
         t = Batch(*util.ragged_rows(rng, na, width, len_a, tu)) if len_a else Batch(
             np.zeros(na + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if tu else None)
@@ -76,7 +85,7 @@ def main():
             from sdr_amd import SdrbError
             for op in range(4):
                 want_s, want_sw = oracle.port().size_op(op, t, a), oracle.port().size_op(op, a, t).T
-                for algo in ("merge", "bitslice", "popcount", "rowtable", "masktable", "lanerows"):
+                for algo in ("merge", "bitslice", "bitslice_long", "popcount", "rowtable", "masktable", "lanerows"):
                     for swap, want in ((False, want_s), (True, want_sw)):
                         try:
                             got = getattr(dt, SIZE[op])(da, swap=swap, algo=algo).cpu().numpy().view(np.uint32)
@@ -132,6 +141,40 @@ def main():
                 print("MISMATCH 64-bit ids", SIZE[op], tag, flush=True)
                 return 1
             checks += 2
+            # ids no table can index: 32-bit ids spread over the whole signed range, 64-bit ids beyond 32 bits
+            # (both keep the rows' order); sizes only depend on which ids rows share
+            if len_a and len_b and width <= 4096:
+                spread = lambda x: (x.astype(np.int64) * 1000003 - 2000000000).astype(np.int32)   # noqa: E731
+                far = lambda x: x.astype(np.int64) * (1 << 33) - (1 << 40)                        # noqa: E731
+                for name, f in (("spread", spread), ("far", far)):
+                    tw = SDRBatch.from_csr(t.off, f(t.ids), t.data)
+                    aw = SDRBatch.from_csr(a.off, f(a.ids), a.data)
+                    for swap in (False, True):
+                        got = getattr(tw, SIZE[op])(aw, swap=swap).cpu().numpy().view(np.uint32)
+                        want = oracle.port().size_op(op, a, t).T if swap else oracle.port().size_op(op, t, a)
+                        if not np.array_equal(got, want):
+                            print("MISMATCH widthless", name, SIZE[op], "swap", swap, tag, flush=True)
+                            return 1
+                        checks += 1
+            # counts as bytes and as 16-bit words: the same numbers, or the refusal when a count could overflow
+            from sdr_amd import SdrbError
+            want = oracle.port().size_op(op, t, a)
+            import torch
+            served = (not tu or op == 1) and 0 < declared <= 4096 and len_b <= 64   # the bit-sliced kernel's shapes
+            for dtype, top in ((torch.uint8, 255), (torch.int16, 65535)):
+                try:
+                    got = getattr(dt, SIZE[op])(da, dtype=dtype).cpu().contiguous().numpy()
+                    got = got.view(np.uint16) if dtype == torch.int16 else got
+                except SdrbError as e:
+                    bound = len_a + len_b if op in (1, 2) else (len_a if op == 3 else min(len_a, len_b))
+                    if e.code != -5 or (served and bound <= top):
+                        print("MISMATCH narrow refusal", SIZE[op], dtype, e.code, tag, flush=True)
+                        return 1
+                    continue
+                if not np.array_equal(got.astype(np.uint32), want):
+                    print("MISMATCH narrow", SIZE[op], dtype, tag, flush=True)
+                    return 1
+                checks += 1
         elif extra == 2 and len_a and len_b:
             ta = util.arith_rows(rng, na, width, len_a)
             aa = util.arith_rows(rng, nb, width, len_b)
