@@ -35,6 +35,12 @@ constexpr int kRowsPerWave = kGroup / kWaves;    // 4
 // rows of A per mask table: 64, or 32 where that makes room for the tile's payloads in LDS;
 // counter tile: [row of B][row of A], padded by one word against bank conflicts
 constexpr int cnt_ld(int tile) { return tile + 1; }
+// Lab switch (tools/exp/build_variant.sh ... -DSDRB_LAB_TILE_STEP=16): a 32-row tile takes only this many rows of A, so
+// that B is streamed 32 / step times as often -- what narrower tiles would cost in passes, with everything else equal.
+#ifndef SDRB_LAB_TILE_STEP
+#define SDRB_LAB_TILE_STEP 0
+#endif
+constexpr int tile_step(int tile) { return SDRB_LAB_TILE_STEP && tile == 32 ? SDRB_LAB_TILE_STEP : tile; }
 
 // dense payload matrix of A: val[i][w] = payload of id w in row i (only read where mask says so)
 __global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restrict__ a_off,
@@ -77,8 +83,8 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     uint16_t* col = reinterpret_cast<uint16_t*>(vals + val_cap);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.y, i0 = tile * kTile;
-    const uint32_t rows_a = na - i0 < (uint32_t)kTile ? na - i0 : (uint32_t)kTile;
+    const uint32_t tile = blockIdx.y, i0 = tile * (uint32_t)tile_step(TILE);
+    const uint32_t rows_a = na - i0 < (uint32_t)tile_step(TILE) ? na - i0 : (uint32_t)tile_step(TILE);
 
     for (uint32_t w = tid; w < width + 1; w += kBlock) mask[w] = 0;
     for (uint32_t e = tid; e < kCntSize; e += kBlock) cnt[e] = 0;
@@ -797,7 +803,7 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
         SDRB_HIP(hipGetLastError());
     }
     const size_t lds = val_cap ? lds_bytes_vals(width, val_cap, tile) : lds_bytes(width);
-    const uint32_t tiles = (na + tile - 1) / tile;
+    const uint32_t tiles = (na + tile_step(tile) - 1) / tile_step(tile);
     const uint32_t groups = (nb + kGroup - 1) / kGroup;
     // one or two resident blocks per CU, shared among the tiles of A
     const uint32_t per_cu = lds <= 80 * 1024 - 256 ? 2u : 1u;
