@@ -18,6 +18,7 @@
 // once per row; the table is rebuilt only when the block moves to another tile of A.
 // The counter of pair (q, jl) lives at cnt[jl * 65 + q]: the lanes of a wave work on one jl and
 // different q, and the write-out reads one q and 64 jl -- both land in 64 different banks.
+#include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
 
@@ -58,7 +59,12 @@ __global__ __launch_bounds__(64) void k_scatter_values(const uint32_t* __restric
 // FILL == false: size ops (counters -> sizes).  FILL == true: ande -- the counter tile starts at the
 // pairs' output offsets and every kept match takes the next slot of its pair; slots of one pair are
 // claimed by concurrent lanes, so a pair's elements are put in id order afterwards (k_sort_pairs_staged).
-template <int MATH, int NIT, bool FILL, bool FLAT, int TILE>
+// LIST (64-row tiles, flat loop, payloads of A needed): no mask at all.  ends[w + 1] (16 bit) is where the list of id w
+// ends -- and the list of id w + 1 starts -- in two parallel arrays: the tile row (a byte) and the payload of every
+// element of the tile that holds the id.  A lane walks the list of its element's id instead of the set bits of a
+// mask.  Where a 64-row mask (8 bytes an id) leaves no room for the payloads and the 32-row mask makes B stream twice
+// as often, the lists (2 bytes an id, 5 an element) fit 64 rows: config 4 streams B once instead of twice.
+template <int MATH, int NIT, bool FILL, bool FLAT, int TILE, bool LIST = false>
 __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val_dense,
     uint32_t na, const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids,
@@ -70,22 +76,83 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
     constexpr bool NEED_B = MATH == kSelfB || MATH == kMul || MATH == kAbsDiff || MATH == kRmulA || MATH == kRmulB;
     constexpr int IT = NIT == 0 ? 1 : NIT;
     static_assert(TILE == 64 || (TILE == 32 && FLAT), "32-row tiles exist for the flat loop only");
+    static_assert(!LIST || (FLAT && TILE == 64 && NEED_A), "lists serve the flat loop over 64-row tiles with payloads of A");
     using mask_t = std::conditional_t<TILE == 64, unsigned long long, uint32_t>;
     constexpr int kTile = TILE, kCntLd = cnt_ld(TILE), kCntSize = kGroup * kCntLd;
     // LDS: mask[width + 1] (mask[width] = 0, the sentinel), cnt[64][TILE + 1], la[TILE], lb[64],
     //      and with FLAT vals[val_cap], col[width + 1]
+    // LIST: ends[width + 2] in place of the mask, then cnt, la, lb, vals[max(val_cap, width + 2)], list_row[val_cap]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     mask_t* mask = reinterpret_cast<mask_t*>(lds_raw);
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(mask + width + 1 + ((width + 1) & 1u));
+    uint16_t* ends = reinterpret_cast<uint16_t*>(lds_raw);
+    uint32_t* cnt = LIST ? reinterpret_cast<uint32_t*>(lds_raw + ((((size_t)width + 2) * 2 + 15) & ~(size_t)15))
+                         : reinterpret_cast<uint32_t*>(mask + width + 1 + ((width + 1) & 1u));
     uint32_t* la = cnt + kCntSize;
     uint32_t* lb = la + kTile;
     float* vals = reinterpret_cast<float*>(lb + kGroup);
-    uint16_t* col = reinterpret_cast<uint16_t*>(vals + val_cap);
+    const uint32_t vals_room = LIST && val_cap < width + 2 ? width + 2 : val_cap;
+    uint16_t* col = reinterpret_cast<uint16_t*>(vals + vals_room);
+    unsigned char* list_row = reinterpret_cast<unsigned char*>(vals + vals_room);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile = blockIdx.y, i0 = tile * (uint32_t)tile_step(TILE);
     const uint32_t rows_a = na - i0 < (uint32_t)tile_step(TILE) ? na - i0 : (uint32_t)tile_step(TILE);
 
+    if constexpr (LIST) {
+        // how many elements of the tile hold each id (32-bit counters where the payloads will be), their running sum as
+        // the lists' starts, then every element takes the next place of its id's list: ends[w + 1] counts up from the
+        // start of list w to its end, which is the start of list w + 1
+        uint32_t* held = reinterpret_cast<uint32_t*>(vals);
+        for (uint32_t w = tid; w < width + 1; w += kBlock) held[w] = 0;
+        for (uint32_t e = tid; e < kCntSize; e += kBlock) cnt[e] = 0;
+        if (tid < kTile) la[tid] = tid < rows_a ? a_off[i0 + tid + 1] - a_off[i0 + tid] : 0u;
+        __syncthreads();
+        for (uint32_t q = wave; q < rows_a; q += kWaves) {
+            const uint32_t beg = a_off[i0 + q], len = a_off[i0 + q + 1] - beg;
+            for (uint32_t k = lane; k < len; k += 64) {
+                const uint32_t id = (uint32_t)a_ids[beg + k];
+                if (id < width) atomicAdd(&held[id], 1u);   // ids outside B's width never match
+            }
+        }
+        __syncthreads();
+        const uint32_t per = (width + kBlock) / kBlock;
+        const uint32_t w0 = tid * per < width + 1 ? tid * per : width + 1;
+        const uint32_t w1 = w0 + per < width + 1 ? w0 + per : width + 1;
+        uint32_t mine = 0;
+        for (uint32_t w = w0; w < w1; ++w) mine += held[w];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) lb[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) run += lb[w];
+        if (tid == 0) ends[0] = 0;
+        for (uint32_t w = w0; w < w1; ++w) {
+            ends[w + 1] = (uint16_t)run;
+            run += held[w];
+        }
+        __syncthreads();
+        uint32_t* ends_words = reinterpret_cast<uint32_t*>(ends);
+        for (uint32_t q = wave; q < rows_a; q += kWaves) {
+            const uint32_t beg = a_off[i0 + q], len = a_off[i0 + q + 1] - beg;
+            for (uint32_t k = lane; k < len; k += 64) {
+                const uint32_t id = (uint32_t)a_ids[beg + k];
+                if (id < width) {
+                    // a 16-bit counter inside a 32-bit word: it never passes 65535 (the host checked), so nothing carries
+                    const uint32_t at = id + 1, hi = at & 1u;
+                    const uint32_t old = atomicAdd(&ends_words[at >> 1], hi ? 0x10000u : 1u);
+                    const uint32_t slot = hi ? old >> 16 : old & 0xffffu;
+                    list_row[slot] = (unsigned char)q;
+                    vals[slot] = a_val[beg + k];
+                }
+            }
+        }
+        __syncthreads();
+    } else {
     for (uint32_t w = tid; w < width + 1; w += kBlock) mask[w] = 0;
     for (uint32_t e = tid; e < kCntSize; e += kBlock) cnt[e] = 0;
     if (tid < kTile) la[tid] = tid < rows_a ? a_off[i0 + tid + 1] - a_off[i0 + tid] : 0u;
@@ -99,7 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
         }
     }
     __syncthreads();
-    if constexpr (FLAT && NEED_A) {
+    }
+    if constexpr (FLAT && NEED_A && !LIST) {
         // col[w] = number of tile elements with an id below w: every thread counts a contiguous piece
         // of the table, the pieces' totals are scanned over the block (lb[] holds the waves' totals)
         const uint32_t per = (width + kBlock) / kBlock;
@@ -177,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
             // The four rows of a wave are one contiguous piece of B's element arrays: its elements are
             // dealt to the lanes, one lane per 32 bits of the mask (two lanes per element with 64-row
             // tiles), whatever row they belong to, so every lane has work and a lane's bit loop is short.
-            constexpr uint32_t LPE = TILE / 32;   // lanes per element
+            constexpr uint32_t LPE = LIST ? 1 : TILE / 32;   // lanes per element
             const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kRowsPerWave));
             uint32_t edge[kRowsPerWave + 1];
 #pragma unroll
@@ -204,6 +272,24 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
                 }
             };
             auto visit_elem = [&](uint32_t id, float vb, uint32_t jl) {
+                if constexpr (LIST) {
+                    uint32_t* pair_cnt = cnt + jl * kCntLd;
+                    const uint32_t end = ends[id + 1];
+                    for (uint32_t at = ends[id]; at < end; ++at) {
+                        const uint32_t q = list_row[at];
+                        const float va = vals[at];
+                        float d;
+                        const bool kept = match_kept_by<MATH>(va, vb, d);
+                        if constexpr (!FILL) {
+                            atomicAdd(&pair_cnt[q], 0x10000u | (kept ? 1u : 0u));
+                        } else if (kept) {
+                            const uint32_t slot = atomicAdd(&pair_cnt[q], 1u);
+                            out_ids[slot] = (int32_t)id;
+                            if constexpr (MATH != kKeepAll) out_data[slot] = d;
+                        }
+                    }
+                    return;
+                }
                 uint32_t m, below = 0;   // below: set bits of the element's mask that other lanes visit first
                 if constexpr (LPE == 2) {
                     const uint2 both = *reinterpret_cast<const uint2*>(&mask[id]);
@@ -305,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_size_mask_table(
             // The fill stores inside the bit loop, and on this hardware a wait for a load also waits for
             // every store issued before it: when the wave's elements fit NP registers per lane they are
             // all fetched before the first store, so that nothing waits for a store until the group ends.
-            constexpr int NP = FILL ? (TILE == 32 ? 24 : 8) : 0;
+            constexpr int NP = FILL ? (LPE == 1 ? 24 : 8) : 0;
             if (stepped) {
                 // the group's rows were dealt above
             } else if (FILL && LPE * n <= (uint32_t)NP * 64u) {
@@ -759,6 +845,13 @@ size_t lds_bytes_vals(uint32_t width, uint32_t val_cap, int tile) {
     return lds_bytes(width, tile) + (size_t)val_cap * 4 + (size_t)(width + 2) * 2;
 }
 
+// the lists of a 64-row tile instead of a mask: ends[width + 2], the counter tile, payloads (the build's counters lie in
+// their place first: width + 2 words at least) and a row byte per element
+size_t lds_bytes_lists(uint32_t width, uint32_t val_cap) {
+    const size_t vals_room = val_cap < width + 2 ? width + 2 : val_cap;
+    return ((((size_t)width + 2) * 2 + 15) & ~(size_t)15) + (size_t)kGroup * cnt_ld(64) * 4 + (64 + kGroup) * 4 + vals_room * 4 + val_cap;
+}
+
 }  // namespace
 
 bool mask_table_applicable(const sdrb_batch* a, const sdrb_batch* b) {
@@ -777,13 +870,17 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     // the tile's payloads in LDS when they fit beside a 64-row table, else beside a 32-row table
     uint32_t val_cap = 0;
     int tile = 64;
+    bool lists = false;   // 64-row tiles kept as per-id lists where the 64-row mask leaves no room for the payloads
     if (need_a && a->max_row_len < 1024) {
         const uint32_t longest = a->max_row_len < width ? a->max_row_len : width;
-        for (int t : {64, 32}) {
-            const uint32_t cap = (uint32_t)t * (longest ? longest : 1u);
-            if (lds_bytes_vals(width, cap, t) <= 160 * 1024 - 512) {
+        static const bool no_lists = getenv("SDRB_MASKTABLE_NO_LISTS") != nullptr;   // measurements of the 32-row tiles
+        for (int t : {64, 0, 32}) {   // 0: the lists
+            const uint32_t cap = (uint32_t)(t ? t : 64) * (longest ? longest : 1u);
+            if (t == 0 ? (!no_lists && cap <= 65535u && lds_bytes_lists(width, cap) <= 160 * 1024 - 512)
+                       : lds_bytes_vals(width, cap, t) <= 160 * 1024 - 512) {
                 val_cap = cap;
-                tile = t;
+                tile = t ? t : 64;
+                lists = t == 0;
                 break;
             }
         }
@@ -802,7 +899,7 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
                            dense);
         SDRB_HIP(hipGetLastError());
     }
-    const size_t lds = val_cap ? lds_bytes_vals(width, val_cap, tile) : lds_bytes(width);
+    const size_t lds = lists ? lds_bytes_lists(width, val_cap) : val_cap ? lds_bytes_vals(width, val_cap, tile) : lds_bytes(width);
     const uint32_t tiles = (na + tile_step(tile) - 1) / tile_step(tile);
     const uint32_t groups = (nb + kGroup - 1) / kGroup;
     // one or two resident blocks per CU, shared among the tiles of A
@@ -827,9 +924,22 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
         if (fill) SDRB_MT_LAUNCH_NFL(M, N, true, false, 64);  \
         else SDRB_MT_LAUNCH_NFL(M, N, false, false, 64);      \
     } while (0)
+#define SDRB_MT_LAUNCH_LISTS(M, F)                                                                                     \
+    do {                                                                                                             \
+        if constexpr (M == kSelfA || M == kMul || M == kAbsDiff || M == kRmulA || M == kRmulB) {                     \
+            SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_size_mask_table<M, 0, F, true, 64, true>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+            hipLaunchKernelGGL((k_size_mask_table<M, 0, F, true, 64, true>), grid, dim3(kBlock), lds, stream,        \
+                               a->d_offsets, a->d_ids, dense, na, b->d_offsets, b->d_ids, b->d_data, nb, width, op,  \
+                               swap ? 1u : 0u, out, ld_out, out_off, out_ids, out_data, a->d_data, val_cap);         \
+        }                                                                                                            \
+    } while (0)
 #define SDRB_MT_LAUNCH(M)                          \
     do {                                           \
-        if (flat && tile == 32) {                  \
+        if (lists) {                               \
+            if (fill) SDRB_MT_LAUNCH_LISTS(M, true);   \
+            else SDRB_MT_LAUNCH_LISTS(M, false);       \
+        } else if (flat && tile == 32) {           \
             if (fill) SDRB_MT_LAUNCH_NFL(M, 0, true, true, 32);  \
             else SDRB_MT_LAUNCH_NFL(M, 0, false, true, 32);      \
         } else if (flat) {                         \
@@ -851,6 +961,7 @@ int run_mask_table(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, 
     default: SDRB_MT_LAUNCH(kRmulB); break;
     }
 #undef SDRB_MT_LAUNCH
+#undef SDRB_MT_LAUNCH_LISTS
 #undef SDRB_MT_LAUNCH_N
 #undef SDRB_MT_LAUNCH_NFL
     SDRB_HIP(hipGetLastError());
