@@ -353,45 +353,42 @@ __global__ __launch_bounds__(kBlock) void k_few_ande_fill(
 //
 // A pair's result is then a subset of A_i's elements, and 64 bits say which: the count pass leaves that POSITION MASK
 // beside the byte count (8 bytes a pair), and the fill expands masks against A_i instead of walking B a second time
-// (164 bytes a row at 2048 / 40).  Every block builds its own tables -- a byte per id with a bit per row of A, and the
-// position of each id in each row -- from A's few hundred ids.
+// (164 bytes a row at 2048 / 40).  Every block builds its own table -- eight bytes an id: for each row of A whether it
+// holds the id, and where -- from A's few hundred ids.
 constexpr int kMaskRows = 8;
 
-template <int NCH, bool SELF_A>
+// ROWS: 1, 2, 4 or 8 -- the rows of A the lane loop is unrolled for (na rounded up)
+template <int NCH, bool SELF_A, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_few_masks_count(
     const uint32_t* __restrict__ a_off, const int32_t* __restrict__ a_ids, const float* __restrict__ a_val, uint32_t na,
     const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint32_t nb, uint32_t wcap,
     unsigned long long* __restrict__ pos_mask, uint8_t* __restrict__ cnt8, uint32_t* __restrict__ group_total, uint32_t n_groups) {
-    // LDS: rows[wcap + 4] bytes (bit q: row q of A holds the id; the word at [wcap] stays zero) |
-    //      pos1[kMaskRows][wcap + 4] bytes: 1 + the position of the id in row q of A, 0 where the row does not hold it |
-    //      wave_part[na][4]
+    // LDS: where[wcap + 1] 64-bit words, byte q of word w: 0x80 | position of id w in row q of A, 0 where the row does not
+    //      hold it (the word at [wcap], the sentinel id's, stays zero) | wave_part[kMaskRows][4]
+    // One 8-byte read an id answers all eight rows; per row the lane shifts the byte's top bit (there or not) by the
+    // byte's low six bits (where) into the pair's mask -- no branch, no loop over matches, every lane the same work.
     extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
-    const uint32_t stride = wcap + 4;
-    uint32_t* rows32 = reinterpret_cast<uint32_t*>(few_lds);
-    unsigned char* rows = few_lds;
-    unsigned char* pos1 = few_lds + stride;
-    uint32_t* wave_part = reinterpret_cast<uint32_t*>(few_lds + stride + (size_t)kMaskRows * stride);
+    unsigned long long* where = reinterpret_cast<unsigned long long*>(few_lds);
+    uint32_t* wave_part = reinterpret_cast<uint32_t*>(few_lds + ((size_t)wcap + 2) * 8);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t w = tid; w < (stride + na * stride) / 4; w += kBlock) rows32[w] = 0;
+    for (uint32_t w = tid; w < wcap + 1; w += kBlock) where[w] = 0;
     __syncthreads();
-    unsigned long long relevant[kMaskRows];   // positions of row q whose own payload is relevant (SELF_A), else all
+    unsigned long long relevant[ROWS];   // positions of row q whose own payload is relevant (SELF_A), else all
 #pragma unroll
-    for (int q = 0; q < kMaskRows; ++q) relevant[q] = ~0ull;
-    for (uint32_t q = 0; q < na; ++q) {
-        const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
-        if (tid < len) {
-            const uint32_t id = (uint32_t)a_ids[beg + tid];
-            if (id < wcap) {   // ids outside B's table cannot match an id of B
-                atomicOr(&rows32[id >> 2], (1u << q) << (8u * (id & 3u)));
-                pos1[q * stride + id] = (unsigned char)(tid + 1);
+    for (int q = 0; q < ROWS; ++q) relevant[q] = ~0ull;
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        if ((uint32_t)q < na) {
+            const uint32_t beg = a_off[q], len = a_off[q + 1] - beg;
+            if (tid < len) {
+                const uint32_t id = (uint32_t)a_ids[beg + tid];
+                if (id < wcap) few_lds[(size_t)id * 8 + q] = (unsigned char)(0x80u | tid);   // ids outside B's table cannot match
             }
-        }
-        if constexpr (SELF_A) {
-            // a match keeps `this`'s payload (UnitData.hpp:43-46) and stays iff that is relevant (SDR.hpp:1017)
-            const bool ok = lane < len && unit_relevant(a_val[beg + lane]);
-            const unsigned long long keep = __builtin_amdgcn_ballot_w64(ok);
-#pragma unroll
-            for (int r = 0; r < kMaskRows; ++r) relevant[r] = q == (uint32_t)r ? keep : relevant[r];
+            if constexpr (SELF_A) {
+                // a match keeps `this`'s payload (UnitData.hpp:43-46) and stays iff that is relevant (SDR.hpp:1017)
+                const bool ok = lane < len && unit_relevant(a_val[beg + lane]);
+                relevant[q] = __builtin_amdgcn_ballot_w64(ok);
+            }
         }
     }
     __syncthreads();
@@ -400,55 +397,31 @@ __global__ __launch_bounds__(kBlock) void k_few_masks_count(
         uint32_t id[8 * NCH], lb;
         float unused[8 * NCH];
         load_row<NCH, false>(b_off, b_ids, nullptr, nb, j0, tid, wcap, id, unused, lb);
-        unsigned long long pm[kMaskRows];
+        unsigned long long pm[ROWS];
 #pragma unroll
-        for (int q = 0; q < kMaskRows; ++q) pm[q] = 0;
-        if (na <= 2) {
-            // one or two rows of A: no branches -- every id reads its position byte in each row (0: not there)
+        for (int q = 0; q < ROWS; ++q) pm[q] = 0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if ((uint32_t)q < na) {
+        for (int k = 0; k < 8 * NCH; ++k) {
+            const unsigned long long w = *reinterpret_cast<const unsigned long long*>(few_lds + id[k] * 2u);   // id[k] = 4 * id
 #pragma unroll
-                    for (int k = 0; k < 8 * NCH; ++k) {
-                        const uint32_t v = pos1[q * stride + (id[k] >> 2)];
-                        pm[q] |= v ? 1ull << (v - 1u) : 0ull;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                uint32_t m[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) m[k] = rows[id[ch * 8 + k] >> 2];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    uint32_t mm = m[k];
-                    while (mm != 0) {
-                        const uint32_t q = (uint32_t)__builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const unsigned long long bit = 1ull << (pos1[q * stride + (id[ch * 8 + k] >> 2)] - 1u);
-#pragma unroll
-                        for (int r = 0; r < kMaskRows; ++r) pm[r] |= q == (uint32_t)r ? bit : 0ull;
-                    }
-                }
+            for (int q = 0; q < ROWS; ++q) {
+                const uint32_t half = q < 4 ? (uint32_t)w : (uint32_t)(w >> 32);
+                const uint32_t there = (half >> (8 * (q & 3) + 7)) & 1u, at = (half >> (8 * (q & 3))) & 63u;
+                pm[q] |= (unsigned long long)there << at;
             }
         }
-        for (uint32_t q = 0; q < na; ++q) {
-            unsigned long long mine = pm[0];
 #pragma unroll
-            for (int r = 1; r < kMaskRows; ++r) mine = q == (uint32_t)r ? pm[r] : mine;
-            unsigned long long rel = relevant[0];
-#pragma unroll
-            for (int r = 1; r < kMaskRows; ++r) rel = q == (uint32_t)r ? relevant[r] : rel;
-            mine &= rel;
-            const uint32_t c = (uint32_t)__builtin_popcountll(mine);
-            if (j < nb) {
-                pos_mask[(uint64_t)q * nb + j] = mine;
-                cnt8[(uint64_t)q * nb + j] = (uint8_t)c;
+        for (int q = 0; q < ROWS; ++q) {
+            if ((uint32_t)q < na) {   // uniform
+                const unsigned long long mine = pm[q] & relevant[q];
+                const uint32_t c = (uint32_t)__builtin_popcountll(mine);
+                if (j < nb) {
+                    pos_mask[(uint64_t)q * nb + j] = mine;
+                    cnt8[(uint64_t)q * nb + j] = (uint8_t)c;
+                }
+                const uint32_t incl = wave_inclusive_scan(c);
+                if (lane == 63) wave_part[q * kWaves + wave] = incl;
             }
-            const uint32_t incl = wave_inclusive_scan(c);
-            if (lane == 63) wave_part[q * kWaves + wave] = incl;
         }
         __syncthreads();
         if (tid < na) {
@@ -533,7 +506,7 @@ bool make_plan(const sdrb_batch* a, const sdrb_batch* b, bool swap, FewPlan* p) 
     if (p->masks) {
         p->tile_bytes = 0;
         p->ntiles = 1;
-        p->lds = (size_t)(1 + kMaskRows) * (p->wcap + 4) + (size_t)kMaskRows * kWaves * 4u;
+        p->lds = ((size_t)p->wcap + 2) * 8 + (size_t)kMaskRows * kWaves * 4u;
         p->n_groups = (uint32_t)((b->n_rows + kBlock - 1) / kBlock);
         const uint32_t per_cu = (uint32_t)((160u * 1024u) / (p->lds + 512));
         const uint32_t resident = 256u * (per_cu < 8u ? per_cu : 8u);
@@ -615,13 +588,20 @@ int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_
         uint8_t* cnt8 = reinterpret_cast<uint8_t*>(ws + mask_bytes_all);
         uint32_t* group_total = reinterpret_cast<uint32_t*>(ws + mask_bytes_all + cnt_bytes);
         const bool self_a = p.math == kSelfA;
-#define SDRB_MASKS_COUNT(NCH, SELF)                                                                                      \
+#define SDRB_MASKS_COUNT_R(NCH, SELF, ROWS)                                                                             \
     do {                                                                                                                 \
         if (p.lds > 64 * 1024)                                                                                           \
-            SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_few_masks_count<NCH, SELF>),                   \
+            SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_few_masks_count<NCH, SELF, ROWS>),             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                       \
-        hipLaunchKernelGGL((k_few_masks_count<NCH, SELF>), dim3(p.grid), dim3(kBlock), p.lds, stream, a->d_offsets, a->d_ids, \
+        hipLaunchKernelGGL((k_few_masks_count<NCH, SELF, ROWS>), dim3(p.grid), dim3(kBlock), p.lds, stream, a->d_offsets, a->d_ids, \
                            a->d_data, na, b->d_offsets, b->d_ids, nb, (uint32_t)p.wcap, pos_mask, cnt8, group_total, p.n_groups); \
+    } while (0)
+#define SDRB_MASKS_COUNT(NCH, SELF)                    \
+    do {                                               \
+        if (na <= 1) SDRB_MASKS_COUNT_R(NCH, SELF, 1); \
+        else if (na <= 2) SDRB_MASKS_COUNT_R(NCH, SELF, 2); \
+        else if (na <= 4) SDRB_MASKS_COUNT_R(NCH, SELF, 4); \
+        else SDRB_MASKS_COUNT_R(NCH, SELF, 8);         \
     } while (0)
         if (p.nch == 5) {
             if (self_a) SDRB_MASKS_COUNT(5, true);
@@ -631,6 +611,7 @@ int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_
             else SDRB_MASKS_COUNT(8, false);
         }
 #undef SDRB_MASKS_COUNT
+#undef SDRB_MASKS_COUNT_R
         SDRB_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, na, p.n_groups, total_dev,
                            out_offsets + (uint64_t)na * nb);
