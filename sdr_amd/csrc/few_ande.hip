@@ -191,13 +191,7 @@ __device__ __forceinline__ void count_rows(const unsigned char* tab, uint32_t co
         if (ch == 0) add8<NPL, true>(planes, kp);
         else add8<NPL, false>(planes, kp);
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        uint32_t x = 0;
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) x |= rotr32(planes[p], r - p) & (0x01010101u << p);
-        count_of[r] = x;
-    }
+    planes_to_bytes<NPL>(planes, count_of);
 }
 
 // (1) bytes per pair and sums per (row of A, group of B)

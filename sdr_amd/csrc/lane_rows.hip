@@ -290,13 +290,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_lane_rows_size(
                 if (ch == 0) add8<NPL, true>(mask_planes, m);
                 else add8<NPL, false>(mask_planes, m);
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                uint32_t y = 0;
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) y |= rotr32(mask_planes[p], r - p) & (0x01010101u << p);
-                match_of[r] = y;
-            }
+            planes_to_bytes<NPL>(mask_planes, match_of);
             asm volatile("" ::: "memory");
         }
 #pragma unroll
@@ -368,13 +362,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_lane_rows_size(
         // unpack: bits r, r+8, r+16, r+24 of plane p -> bit p of bytes 0..3 of word r; then one coalesced
         // 256-byte segment per wave per row of A, in row order
         uint32_t count_of[8];
+        planes_to_bytes<NPL>(planes, count_of);
+        if constexpr (COUNT == kCountBoth) {   // four byte-wide sums at once: both counts stay below 128
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) x |= rotr32(planes[p], r - p) & (0x01010101u << p);
-            if constexpr (COUNT == kCountBoth) x += match_of[r];   // four byte-wide sums at once: both counts stay below 128
-            count_of[r] = x;
+            for (int r = 0; r < 8; ++r) count_of[r] += match_of[r];
         }
         uint32_t la_vec = 0;
         if constexpr (COUNT != kCountKept)

@@ -47,8 +47,9 @@ struct NarrowLane {
     uint32_t sel_a, sel_b;     // byte selectors of the two transpose steps for this lane of its quad
     uint32_t row_in_quad;      // lane & 3: which of the four rows r, r+8, r+16, r+24 the lane stores
     uint32_t lb_lo, lb_hi;     // |B_j| of the quad's four rows of B, packed as bytes (lb_lo) or 16-bit pairs (lb_lo, lb_hi)
-    uint32_t voff;             // byte offset of the lane's store inside a row group: row_in_quad * 8 rows + its columns
-    bool cols_ok;              // the quad's rows of B exist
+    uint32_t voff;             // byte offset of the lane's store inside a row group: row_in_quad * 8 rows + its columns;
+                               // 0xF0000000 (past every buffer size, which end below 0xC8000000) when the quad's rows of B do not exist
+    uint32_t cols_bytes;       // bytes of a row of the output that this block's rows of B cover, whole quads (uniform)
 };
 
 template <int NCH, int MODE, int OUTB>
@@ -80,20 +81,15 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
         }
     }
     // unpack one 32-row half at a time: bits r, r+8, r+16, r+24 of plane p -> bit p+SH of
-    // bytes 0..3 of acc[r]; then store in row order of A, advancing the row pointer
+    // bytes 0..3 of acc[r] (planes_to_bytes); then store in row order of A, advancing the row pointer
     char* row_ptr = tile_out;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         uint32_t acc[8];
+        planes_to_bytes<NPL>(h ? hi : lo, acc);
+        if constexpr (SH != 0) {   // counts doubled (they stay below 128, nothing leaves its byte)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint32_t a = 0;
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                const uint32_t w = h ? hi[p] : lo[p];
-                a |= rotr32(w, r - p - SH) & (0x01010101u << (p + SH));
-            }
-            acc[r] = a;
+            for (int r = 0; r < 8; ++r) acc[r] <<= SH;
         }
         if constexpr (OUTB != 4) {
 #pragma unroll
@@ -108,12 +104,18 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
                 const uint32_t q = 32u * h + r + 8u * narrow.row_in_quad;
                 uint32_t la = 0;
                 if constexpr (MODE != 0) la = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q * 4u), (int)la_vec);
+                // Stores are unconditional: a branch around them would make every later wait for a load (the next tile
+                // of the table) a wait for all stores before it.  What must not be written is cut off by the buffer's
+                // size instead -- the rows of A past the tile's last (a uniform count of the row groups 8 apart that
+                // exist from row 32 h + r on) -- and by an offset past every size for the lanes whose rows of B do not exist.
                 char* group = row_ptr + (uint64_t)r * row_bytes;
-                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(group, 0, (int)0xFFFFFFFFu, 0x00020000);
-                const bool live = narrow.cols_ok && q < rows_in_tile;
+                const int rows_left = (int)rows_in_tile - (32 * h + r);
+                const uint32_t groups = rows_left <= 0 ? 0u : rows_left > 24 ? 4u : (uint32_t)(rows_left + 7) / 8u;
+                const uint32_t size = groups ? (groups - 1u) * 8u * (uint32_t)row_bytes + narrow.cols_bytes : 0u;
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(group, 0, (int)size, 0x00020000);
                 if constexpr (OUTB == 1) {
                     if constexpr (MODE != 0) u = la * 0x01010101u + narrow.lb_lo - u;
-                    if (live) __builtin_amdgcn_raw_buffer_store_b32(u, rsrc, (int)narrow.voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(u, rsrc, (int)narrow.voff, 0, 0);
                 } else {
                     uint32_t lo2 = (u & 0xffu) | ((u & 0xff00u) << 8), hi2 = ((u >> 16) & 0xffu) | ((u >> 8) & 0xff0000u);
                     if constexpr (MODE != 0) {
@@ -122,7 +124,7 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
                     }
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                     const u32x2 both = {lo2, hi2};
-                    if (live) __builtin_amdgcn_raw_buffer_store_b64(both, rsrc, (int)narrow.voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(both, rsrc, (int)narrow.voff, 0, 0);
                 }
             }
             row_ptr += 32 * row_bytes;
@@ -151,7 +153,10 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
 // WCAP : table words per tile; one tile fills one LDS buffer, two buffers alternate
 // OUTB : bytes per count in `out` (4: uint32, the reference's size_t narrowed; 1 / 2: see tile_body)
 template <int NCH, int MODE, int WCAP, int OUTB>
-__global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_bitslice(
+#ifndef SDRB_BS_NARROW_WAVES
+#define SDRB_BS_NARROW_WAVES kMinWaves
+#endif
+__global__ __launch_bounds__(kBlock, WCAP <= 2048 ? (OUTB == 4 ? kMinWaves : SDRB_BS_NARROW_WAVES) : 2) void k_size_bitslice(
     const uint32_t* __restrict__ b_off, const int32_t* __restrict__ b_ids, uint64_t nb,
     const u64* __restrict__ table, const uint32_t* __restrict__ a_len, uint32_t ntiles,
     uint32_t tiles_per_block, uint32_t na, uint32_t use_la, uint32_t use_lb,
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? kMinWaves : 2) void k_size_b
             narrow.lb_lo = l0 | (l1 << 16);
             narrow.lb_hi = l2 | (l3 << 16);
         }
-        narrow.voff = (uint32_t)((tid & 3) * 8u * row_bytes) + (tid & ~3u) * OUTB;
-        narrow.cols_ok = (uint64_t)(tid & ~3u) < rows_here;
+        narrow.voff = (uint64_t)(tid & ~3u) < rows_here ? (uint32_t)((tid & 3) * 8u * row_bytes) + (tid & ~3u) * OUTB : 0xF0000000u;
+        narrow.cols_bytes = (((uint32_t)rows_here + 3u) & ~3u) * OUTB;
     }
 
     for (uint32_t t = t0; t < t1; ++t) {

@@ -31,6 +31,30 @@ __device__ __forceinline__ uint32_t rotr32(uint32_t x, int s) {
     return __builtin_amdgcn_alignbit(x, x, (uint32_t)(s & 31));
 }
 
+// Planes -> bytes.  acc[r] gets, in byte k, the count of column 8k + r: bit p of that byte is bit 8k + r of plane p.
+// That is the transpose of an 8 x 8 bit matrix (planes down, columns of a byte across) in each of the word's four bytes
+// at once: three rounds of block swaps between registers 4, 2 and 1 apart (planes past NPL are zero, and what only
+// moves zeros folds away).  About 50 instructions for six planes, against two a (plane, r) term -- 96 -- when every
+// term is shifted and masked on its own.
+__device__ __forceinline__ void swap_bits(uint32_t& a, uint32_t& b, int d, uint32_t m) {
+    const uint32_t t = ((a >> d) ^ b) & m;
+    b ^= t;
+    a ^= t << d;
+}
+template <int NPL>
+__device__ __forceinline__ void planes_to_bytes(const uint32_t (&pl)[NPL], uint32_t (&acc)[8]) {
+    static_assert(NPL <= 8, "a byte holds eight planes");
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = p < NPL ? pl[p] : 0u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) swap_bits(acc[p], acc[p + 4], 4, 0x0F0F0F0Fu);
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+        if ((p & 2) == 0) swap_bits(acc[p], acc[p + 2], 2, 0x33333333u);
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) swap_bits(acc[p], acc[p + 1], 1, 0x55555555u);
+}
+
 // Adds eight 32-column bit words into the vertical counter P (Harley-Seal step):
 // P[0..2] keep count mod 8, the weight-8 carry ripples into P[3..].
 template <int NPL, bool FIRST>
