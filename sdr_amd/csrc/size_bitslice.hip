@@ -111,13 +111,18 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
                 char* group = row_ptr + (uint64_t)r * row_bytes;
                 const int rows_left = (int)rows_in_tile - (32 * h + r);
                 const uint32_t groups = rows_left <= 0 ? 0u : rows_left > 24 ? 4u : (uint32_t)(rows_left + 7) / 8u;
+#ifdef SDRB_LAB_NO_NARROW_STORES   // timing only: everything but the stores (ld_out is a multiple of 4: never 6 bytes a row)
+                const uint32_t size = groups && row_bytes == 6u ? (groups - 1u) * 8u * (uint32_t)row_bytes + narrow.cols_bytes : 0u;
+#else
                 const uint32_t size = groups ? (groups - 1u) * 8u * (uint32_t)row_bytes + narrow.cols_bytes : 0u;
+#endif
                 __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(group, 0, (int)size, 0x00020000);
                 if constexpr (OUTB == 1) {
                     if constexpr (MODE != 0) u = la * 0x01010101u + narrow.lb_lo - u;
                     __builtin_amdgcn_raw_buffer_store_b32(u, rsrc, (int)narrow.voff, 0, 0);
                 } else {
-                    uint32_t lo2 = (u & 0xffu) | ((u & 0xff00u) << 8), hi2 = ((u >> 16) & 0xffu) | ((u >> 8) & 0xff0000u);
+                    // bytes 0, 1 and 2, 3 widened to 16-bit pairs: one byte permute each (selector 0x0c yields a zero byte)
+                    uint32_t lo2 = __builtin_amdgcn_perm(0u, u, 0x0c010c00u), hi2 = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
                     if constexpr (MODE != 0) {
                         lo2 = la * 0x00010001u + narrow.lb_lo - lo2;
                         hi2 = la * 0x00010001u + narrow.lb_hi - hi2;
