@@ -83,3 +83,22 @@ def test_element_ops_of_widthless_batches_still_equal_the_oracle():
         w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
         assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids), name
         assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("name,wide", [("EE", False), ("UU", False), ("EE", True)])
+def test_large_database_takes_chunks_that_fit_the_table_in_lds(name, wide):
+    """More labels than a table in LDS holds (300 rows of 40 ids) against more than 2^20 elements: the rows of A are cut
+    into chunks whose table fits LDS; 64-bit ids beyond 32 bits take the narrower limit of their wider keys."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(23)
+    t = Batch(*util.ragged_rows(rng, 300, 3000, 40, tu))
+    a = Batch(*util.ragged_rows(rng, 60000, 3000, 40, au))
+    if wide:
+        dt = SDRBatch.from_csr(t.off, spread(t.ids, 0x100000003, 0x4000000000), t.data)
+        da = SDRBatch.from_csr(a.off, spread(a.ids, 0x100000003, 0x4000000000), a.data)
+    else:
+        dt = SDRBatch.from_csr(t.off, spread(t.ids, 700001, 1000000000).astype(np.int32), t.data)
+        da = SDRBatch.from_csr(a.off, spread(a.ids, 700001, 1000000000).astype(np.int32), a.data)
+    assert a.ids.size > 1 << 20
+    assert np.array_equal(sizes(XOR, dt, da), oracle.port().size_op(XOR, t, a))
+    assert np.array_equal(sizes(RM, dt, da, swap=True), oracle.port().size_op(RM, a, t).T)
