@@ -98,8 +98,12 @@ int sdrb_device_count(int* count);
 /*
  * Creates an empty batch on `device`.
  * width > 0 declares that every id lies in [0, width) (checked at upload); width == 0
- * means arbitrary signed ids (SDRElem.hpp:15,73-75).  The table-driven kernels need a
- * declared width; without one only the merge kernels are used.
+ * means arbitrary signed ids (SDRElem.hpp:15,73-75).  The table-driven kernels index
+ * tables by id.  A batch without a declared width whose uploaded ids are all non-negative
+ * is served by them as if largest id + 1 had been declared (sdrb_batch_info still reports
+ * 0, and the transpose still asks for a declared width); with a negative id, or ids beyond
+ * every table, size operations go through small per-call labels and the table kernels,
+ * element operations through the per-pair merge kernels.
  * Replaces: the container side of SDR<SDRElem<int,Data>, Container> (SDR.hpp:26-27,573);
  * the struct-of-arrays layout mirrors IDContiguousContainer.hpp:246-250.
  */

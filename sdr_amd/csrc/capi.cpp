@@ -103,6 +103,7 @@ void free_batch_storage(sdrb_batch* b) {
     b->max_row_len = 0;
     b->min_id = 0;
     b->max_id = -1;
+    settle_width(b);
 }
 
 // Makes room for n_rows rows / nnz elements, keeping the current allocation when it is large
@@ -361,6 +362,7 @@ int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out
     }
     b->device = device;
     b->width = width;
+    b->width_declared = width > 0;
     b->data_kind = data_kind;
     *out = b;
     return SDRB_OK;
@@ -429,7 +431,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
         return SDRB_ERR_PAYLOAD_RANGE;
     }
     const bool any = st.max_len > 0;
-    if (batch->width > 0 && any && (st.min_id < 0 || st.max_id >= batch->width)) {
+    if (batch->width_declared && any && (st.min_id < 0 || st.max_id >= batch->width)) {
         set_error("id outside the declared width: ids span [%d, %d], width %d", st.min_id, st.max_id,
                   batch->width);
         return SDRB_ERR_ID_RANGE;
@@ -448,6 +450,7 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
     batch->max_row_len = st.max_len;
     batch->min_id = any ? st.min_id : 0;
     batch->max_id = any ? st.max_id : -1;
+    settle_width(batch);
     return SDRB_OK;
 }
 
@@ -465,7 +468,7 @@ int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz
         set_error("batch too large for 32-bit offsets");
         return SDRB_ERR_OVERFLOW;
     }
-    if (batch->width > 0 && nnz && (min_id < 0 || max_id >= batch->width)) {
+    if (batch->width_declared && nnz && (min_id < 0 || max_id >= batch->width)) {
         set_error("id outside the declared width: ids span [%d, %d], width %d", min_id, max_id, batch->width);
         return SDRB_ERR_ID_RANGE;
     }
@@ -480,6 +483,7 @@ int sdrb_batch_adopt_device_csr(sdrb_batch* batch, uint64_t n_rows, uint64_t nnz
     batch->max_row_len = max_row_len;
     batch->min_id = nnz ? min_id : 0;
     batch->max_id = nnz ? max_id : -1;
+    if (!batch->width_declared) batch->width = 0;   // the id span is the caller's word here: no width is derived from it
     return SDRB_OK;
 }
 
@@ -492,7 +496,7 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
     if (device) *device = batch->device;
     if (n_rows) *n_rows = batch->n_rows;
     if (nnz) *nnz = batch->nnz;
-    if (width) *width = batch->width;
+    if (width) *width = declared_width(batch);
     if (data_kind) *data_kind = batch->data_kind;
     if (max_row_len) *max_row_len = batch->max_row_len;
     return SDRB_OK;
@@ -779,7 +783,7 @@ static int sdrb_batch_transpose_impl(const sdrb_batch* src, sdrb_batch* dst, voi
         return SDRB_ERR_INVALID_ARG;
     }
     if (check_ids32(src, dst, "sdrb_batch_transpose") != SDRB_OK) return SDRB_ERR_UNSUPPORTED;
-    if (src->width <= 0 || src->device != dst->device || src->data_kind != dst->data_kind) {
+    if (!src->width_declared || src->device != dst->device || src->data_kind != dst->data_kind) {
         set_error("sdrb_batch_transpose: src needs a declared width; dst the same device and payload kind");
         return SDRB_ERR_INVALID_ARG;
     }
@@ -804,6 +808,7 @@ static int sdrb_batch_transpose_impl(const sdrb_batch* src, sdrb_batch* dst, voi
     dst->nnz = src->nnz;
     dst->max_row_len = longest;
     dst->width = (int32_t)src->n_rows;
+    dst->width_declared = true;
     dst->min_id = 0;                                   // bounds of the row numbers (not necessarily attained)
     dst->max_id = src->nnz ? (int32_t)src->n_rows - 1 : -1;
     return SDRB_OK;

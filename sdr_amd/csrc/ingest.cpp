@@ -849,7 +849,7 @@ int upload_rows(sdrb_batch* batch, uint64_t n_rows, const uint64_t* off, const I
     Findings all;
     if (bytes < kSmallBytes) {
         // check first, then copy: nothing on the device is touched by a refused batch
-        int rc = check_rows<Id>(n_rows, off, ids, data, batch->width, batch->data_kind, &all);
+        int rc = check_rows<Id>(n_rows, off, ids, data, declared_width(batch), batch->data_kind, &all);
         if (rc != SDRB_OK) return rc;
         DeviceGuard guard(batch->device);
         if (!guard.ok) {
@@ -878,7 +878,7 @@ int upload_rows(sdrb_batch* batch, uint64_t n_rows, const uint64_t* off, const I
     rc = copy_by_team<Id>(batch, n_rows, off, ids, data, bytes, s);
     if (rc == SDRB_OK) rc = check_on_device<Id>(batch, n_rows, nnz, off, ids, data, s, &all);
     else (void)hipStreamSynchronize(s);
-    if (rc == SDRB_OK) rc = verdict<Id>(all, batch->width, batch->data_kind, off, ids, data);
+    if (rc == SDRB_OK) rc = verdict<Id>(all, declared_width(batch), batch->data_kind, off, ids, data);
     if (rc != SDRB_OK) {
         clear_batch_rows(batch);   // parts of the refused rows may have reached the device: the batch holds none
         return rc;
@@ -936,6 +936,7 @@ static int upload_csr_impl(sdrb_batch* batch, uint64_t n_rows, const uint64_t* r
     batch->max_row_len = f.max_len;
     batch->min_id = any ? (int32_t)f.min_id : 0;
     batch->max_id = any ? (int32_t)f.max_id : -1;
+    settle_width(batch);
     return SDRB_OK;
 }
 

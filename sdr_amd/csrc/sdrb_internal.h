@@ -17,7 +17,9 @@
 
 struct sdrb_batch {
     int device = 0;
-    int32_t width = 0;     // 0 = undeclared
+    int32_t width = 0;     // what the kernels take as the width: the declared one, or, for a batch created without one,
+                           // largest id + 1 once rows without a negative id have been uploaded (settle_width); else 0
+    bool width_declared = false;   // `width` was given at creation (ids are checked against it, callers see it)
     int data_kind = SDRB_DATA_EMPTY;
     int id_bits = 32;      // 64: d_ids points at int64 ids (min_id/max_id unused); see `narrow`
     uint64_t n_rows = 0;
@@ -47,6 +49,15 @@ struct sdrb_batch {
 };
 
 namespace sdrb {
+
+// A batch created without a width whose ids are all non-negative is served as if largest id + 1 had been declared:
+// every table kernel then applies to it (ids of the other batch beyond that width never match, as with any declared
+// width).  Called by the uploads that have looked at every id; a negative id leaves the width at 0.
+inline void settle_width(sdrb_batch* b) {
+    if (b->width_declared) return;
+    b->width = (b->nnz != 0 && b->min_id >= 0 && b->max_id < 0x7FFFFFFF) ? b->max_id + 1 : 0;
+}
+inline int32_t declared_width(const sdrb_batch* b) { return b->width_declared ? b->width : 0; }
 
 // does the batch carry a float per element (UnitData or ArithData<float>)?
 inline bool has_payload(const sdrb_batch* b) { return b->data_kind != SDRB_DATA_EMPTY; }

@@ -91,10 +91,13 @@ def main():
             d_csr = sdr_amd.synth_csr(1, 0, nd, width, active, unit)
             out = torch.empty((nq, nd), dtype=torch.int32, device="cuda:0")
             times = {}
-            for label, w in (("declared", width), ("widthless", 0)):
-                q, d = SDRBatch.from_csr(*q_csr, width=w), SDRBatch.from_csr(*d_csr, width=w)
+            # "undeclared": no width given, no negative id -- the library derives one (largest id + 1);
+            # "widthless": the same rows with every id moved down by 1000, so that there is no width to derive
+            for label, w, shift in (("declared", width, 0), ("undeclared", 0, 0), ("widthless", 0, 1000)):
+                q = SDRBatch.from_csr(q_csr[0], q_csr[1] - shift, q_csr[2], width=w)
+                d = SDRBatch.from_csr(d_csr[0], d_csr[1] - shift, d_csr[2], width=w)
                 times[label], _ = timed(lambda: getattr(q, sname)(d, out=out), args.reps)
-                if w == 0:
+                if shift:
                     ref = out.clone()
                     times["merge"], _ = timed(lambda: getattr(q, sname)(d, out=out, algo="merge"), max(1, args.reps // 2))
                     same = bool(torch.equal(ref, out))
@@ -103,7 +106,7 @@ def main():
             nbytes = (nd + nq) * (eb * active + 4) + nq * nd * 4
             print(json.dumps({"case": "widthless", "shape": tag, "queries": nq, "rows": nd, "width": width, "active": active,
                               "unit": unit, "op": sname, "declared_ms": round(times["declared"], 4),
-                              "widthless_ms": round(times["widthless"], 4), "merge_ms": round(times["merge"], 4),
+                              "undeclared_ms": round(times["undeclared"], 4), "widthless_ms": round(times["widthless"], 4), "merge_ms": round(times["merge"], 4),
                               "speedup_over_merge": round(times["merge"] / times["widthless"], 1), "equal": same,
                               "widthless_GBps": round(nbytes / times["widthless"] / 1e6, 1),
                               "merge_pair_ops_per_s": round(nq * nd / (times["merge"] * 1e-3), 0)}), flush=True)

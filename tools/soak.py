@@ -59,6 +59,10 @@ def main():
             np.zeros(na + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if tu else None)
         a = Batch(*util.ragged_rows(rng, nb, width, len_b, au)) if len_b else Batch(
             np.zeros(nb + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if au else None)
+        if declared == 0 and rng.random() < 0.5 and not long_rows:
+            # no width to derive either: some ids negative (labels for the sizes, the merges for the elements)
+            t = Batch(t.off, t.ids - 3, t.data)
+            a = Batch(a.off, a.ids - 3, a.data)
         dt = SDRBatch.from_csr(t.off, t.ids, t.data, width=declared)
         da = SDRBatch.from_csr(a.off, a.ids, a.data, width=declared)
         tag = dict(seed=seed, width=width, declared=declared, na=na, nb=nb, len_a=len_a, len_b=len_b, tu=tu, au=au)
