@@ -381,7 +381,34 @@ def secondary_configs(dev) -> dict:
                                            workload=f"{name}: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData",
                                            elements=res.total)
             del res, counts
-    del d
+    # ids without a usable width (every id moved below zero: nothing to declare or derive), a 64-query slab of the
+    # headline shape: the default choice (small labels, then the table kernels) beside the per-pair merge kernel it
+    # replaced, the same rows with a declared width, and with none declared but none negative (one is derived)
+    nq = 64
+    q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE)
+    counts = torch.empty((nq, nd), dtype=torch.int32, device=dev)
+    q = SDRBatch.from_csr(*q_csr, width=WIDTH)
+    ms_declared, _ = _timed(lambda: q.ands(d, out=counts))
+    want = counts.clone()
+    qu, du = SDRBatch.from_csr(*q_csr), SDRBatch.from_csr(*d_csr)
+    ms_undeclared, _ = _timed(lambda: qu.ands(du, out=counts))
+    same = bool(torch.equal(counts, want))
+    qn = SDRBatch.from_csr(q_csr[0], q_csr[1] - 1000, None)
+    dn = SDRBatch.from_csr(d_csr[0], d_csr[1] - 1000, None)
+    ms_labels, _ = _timed(lambda: qn.ands(dn, out=counts))
+    same = same and bool(torch.equal(counts, want))
+    ms_merge, _ = _timed(lambda: qn.ands(dn, out=counts, algo="merge"), reps=3)
+    same = same and bool(torch.equal(counts, want))
+    cols = torch.as_tensor(sample, device=dev)
+    same = same and bool(np.array_equal(
+        want[:, cols].cpu().numpy().view(np.uint32),
+        oracle.port().size_op(oracle.AND, oracle.Batch(*q_csr[:2], None), oracle.Batch(*_gather_rows(d_csr[0], d_csr[1], sample)[:2], None))))
+    entry = line(ms_labels, (nd + nq) * (4 * ACTIVE + 4) + nq * nd * 4, same,
+                 workload=f"ands: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData, ids moved below zero and no width declared")
+    entry.update(declared_width_ms=ms_declared, undeclared_nonnegative_ms=ms_undeclared, merge_kernel_ms=ms_merge,
+                 merge_pair_ops_per_s=nq * nd / (ms_merge * 1e-3))
+    out["widthless_ands_q64"] = entry
+    del d, q, qu, du, qn, dn, counts, want
     torch.cuda.empty_cache()
 
     # config 4: UnitData 16384 / 328 active, one GPU's 128 Ki rows of the 1 Mi-row database, 64 queries
