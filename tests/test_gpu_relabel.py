@@ -102,3 +102,26 @@ def test_large_database_takes_chunks_that_fit_the_table_in_lds(name, wide):
     assert a.ids.size > 1 << 20
     assert np.array_equal(sizes(XOR, dt, da), oracle.port().size_op(XOR, t, a))
     assert np.array_equal(sizes(RM, dt, da, swap=True), oracle.port().size_op(RM, a, t).T)
+
+
+def test_undeclared_width_is_derived_from_the_ids_whatever_their_size():
+    """No width declared, no negative id: the library serves the batch as if largest id + 1 had been declared.  Small ids
+    reach the table kernels (sizes and elements); ids spread up to 1.5e9 must still come out right (a derived width far
+    beyond every table)."""
+    rng = np.random.default_rng(29)
+    t = Batch(*util.ragged_rows(rng, 20, 3000, 40, True))
+    a = Batch(*util.ragged_rows(rng, 700, 3000, 40, True))
+    for factor in (1, 500000):
+        ts, as_ = Batch(t.off, (t.ids.astype(np.int64) * factor).astype(np.int32), t.data), Batch(a.off, (a.ids.astype(np.int64) * factor).astype(np.int32), a.data)
+        dt, da = SDRBatch.from_csr(ts.off, ts.ids, ts.data), SDRBatch.from_csr(as_.off, as_.ids, as_.data)
+        assert dt.width == 0 and da.width == 0          # what callers see stays "undeclared"
+        for op in (AND, OR, XOR, RM):
+            assert np.array_equal(sizes(op, dt, da), oracle.port().size_op(op, ts, as_)), (NAMES[op], factor)
+        for name, op in (("ande", AND), ("ore", OR), ("rme", RM)):
+            off, ids, data = getattr(dt, name)(da).to_host()
+            w_off, w_ids, w_data = oracle.port().elem_op(op, ts, as_)
+            assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids), (name, factor)
+            assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), (name, factor)
+    # the table kernels can be asked for by name once a width is derived
+    small_t, small_a = SDRBatch.from_csr(t.off, t.ids, None), SDRBatch.from_csr(a.off, a.ids, None)
+    assert np.array_equal(sizes(AND, small_t, small_a, algo="bitslice"), oracle.port().size_op(AND, Batch(t.off, t.ids, None), Batch(a.off, a.ids, None)))
