@@ -120,6 +120,7 @@ int sdrb_batch_create(int device, int32_t width, int data_kind, sdrb_batch** out
  * Large batches are checked and staged by a team of host threads (at most 16, or SDRB_HOST_THREADS) through
  * page-locked buffers while earlier pieces are already crossing the bus; such a batch, when it is refused, leaves
  * the handle without rows (small batches are checked before anything is copied and leave the handle as it was).
+ * ids / data that already lie in page-locked host memory are copied as they are, without staging.
  */
 int sdrb_batch_upload_csr(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
                           const int32_t* ids, const float* data, void* stream);

@@ -779,6 +779,15 @@ void check_by_team(int data_kind, uint64_t n_rows, const uint64_t* off, const Id
 // Copies the three arrays into the batch's storage (reserved by the caller, its device current) through the ring of
 // staging buffers.  The transfers run on the library's copy streams, after what `s` held before the call; on return
 // `s` waits for them (they are enqueued, not waited for by the host).
+bool page_locked(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();   // ordinary host memory is an error to this call on some runtimes: not one of ours
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 template <typename Id>
 int copy_by_team(sdrb_batch* batch, uint64_t n_rows, const uint64_t* off, const Id* ids, const float* data, uint64_t bytes,
                  hipStream_t s) {
@@ -788,8 +797,12 @@ int copy_by_team(sdrb_batch* batch, uint64_t n_rows, const uint64_t* off, const 
     const int threads = std::min(team_size(bytes), 9);
     std::vector<Piece> pieces;
     size_t small = (size_t)threads;
-    add_pieces(&pieces, batch->d_ids, ids, nnz * sizeof(Id), false, &small);
-    if (has_payload(batch)) add_pieces(&pieces, batch->d_data, data, nnz * sizeof(float), false, &small);
+    // An array the caller already holds in page-locked memory needs no staging: it crosses the bus in one copy of its
+    // own (the offsets are always staged: they are narrowed on the way).  The upload returns after its checks have run
+    // on the device, which is after these copies.
+    const bool ids_direct = nnz != 0 && page_locked(ids), data_direct = has_payload(batch) && nnz != 0 && page_locked(data);
+    if (!ids_direct) add_pieces(&pieces, batch->d_ids, ids, nnz * sizeof(Id), false, &small);
+    if (has_payload(batch) && !data_direct) add_pieces(&pieces, batch->d_data, data, nnz * sizeof(float), false, &small);
     add_pieces(&pieces, batch->d_offsets, off, (n_rows + 1) * sizeof(uint32_t), true, &small);
     CopyJob job(std::move(pieces));
     std::lock_guard<std::mutex> stage_lock(g_stage_mutex);
@@ -798,6 +811,8 @@ int copy_by_team(sdrb_batch* batch, uint64_t n_rows, const uint64_t* off, const 
     // the copy streams start after the work already enqueued on s (it may still read the storage written here)
     SDRB_HIP(hipEventRecord(g_order_event[device][kCopyStreams], s));
     for (int k = 0; k < kCopyStreams; ++k) SDRB_HIP(hipStreamWaitEvent(g_copy_stream[device][k], g_order_event[device][kCopyStreams], 0));
+    if (ids_direct) SDRB_HIP(hipMemcpyAsync(batch->d_ids, ids, nnz * sizeof(Id), hipMemcpyHostToDevice, g_copy_stream[device][kCopyStreams - 1]));
+    if (data_direct) SDRB_HIP(hipMemcpyAsync(batch->d_data, data, nnz * sizeof(float), hipMemcpyHostToDevice, g_copy_stream[device][kCopyStreams - 2]));
     Team team;
     CopyJob* jp = &job;
     team.start(threads > 1 ? threads - 1 : 1, [jp](int) { run_stager(jp); });

@@ -143,3 +143,25 @@ def test_stream_release_frees_the_scratch_of_a_stream():
         again = q.ands(d, stream=s).cpu().numpy()
     assert np.array_equal(first, again)
     assert lib.sdrb_stream_release(0, C.c_void_p(s.cuda_stream)) == 0
+
+
+@pytest.mark.parametrize("with_data", [False, True])
+def test_upload_from_page_locked_arrays(with_data):
+    """Arrays the caller already holds in page-locked memory are copied without staging: the same rows must arrive, and a
+    refusal must still leave the batch empty."""
+    off, ids, data = sdr_amd.synth_csr(3, 0, 300_000, 2048, 40, with_data)
+    ids_pin = torch.from_numpy(ids).pin_memory().numpy()
+    data_pin = torch.from_numpy(data).pin_memory().numpy() if with_data else None
+    b = SDRBatch.from_csr(off, ids_pin, data_pin, width=2048)
+    d_off, d_ids, d_data = device_arrays(b)
+    assert np.array_equal(d_off.astype(np.uint64), off) and np.array_equal(d_ids, ids)
+    if with_data:
+        assert np.array_equal(d_data.view(np.uint32), data.view(np.uint32))
+    bad = ids_pin.copy()
+    bad[5_000_001] = bad[5_000_000]              # a repeated id inside a row (rows hold 40 ids: both lie in row 125000)
+    bad_pin = torch.from_numpy(bad).pin_memory().numpy()
+    with pytest.raises(sdr_amd.SdrbError) as e:
+        b.upload(off, bad_pin, data_pin)
+    assert e.value.code == -2 and "125000" in str(e.value)
+    b._refresh_info()
+    assert b.n_rows == 0 and b.nnz == 0
