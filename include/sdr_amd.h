@@ -175,6 +175,14 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
 int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id);
 
 /*
+ * The width the table kernels index this batch by: the declared width; for a batch created without one, largest id + 1
+ * once rows without a negative id have been uploaded; 0 when there is none (negative ids, 64-bit ids, adopted rows).
+ * A caller that sizes buffers by the expected number of matches (sdrb_ande_few) divides by this.
+ * No counterpart in the reference, whose ids need no width (SDRElem.hpp:15).
+ */
+int sdrb_batch_table_width(const sdrb_batch* batch, int32_t* width);
+
+/*
  * Copies the packed CSR into caller buffers on the same device (device-to-device, ordered on
  * `stream`): row_offsets[n_rows+1], ids[nnz], data[nnz] (UnitData batches; may be NULL otherwise).
  * This is the sending side of an exchange whose receiving side is sdrb_batch_adopt_device_csr.

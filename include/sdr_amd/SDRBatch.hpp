@@ -885,7 +885,8 @@ class SDRBatch {
         int32_t b_width = 0;
         uint32_t b_longest = 0;
         check(sdrb_batch_info(h_, nullptr, nullptr, &a_nnz, nullptr, nullptr, nullptr));
-        check(sdrb_batch_info(db.h_, nullptr, nullptr, &b_nnz, &b_width, nullptr, &b_longest));
+        check(sdrb_batch_info(db.h_, nullptr, nullptr, &b_nnz, nullptr, nullptr, &b_longest));
+        check(sdrb_batch_table_width(db.h_, &b_width));   // the declared width, or the one derived from the ids
         const bool few = op == SDRB_OP_AND && n_rows_ >= 1 && n_rows_ <= 32 && b_width > 0 && b_width <= 4096 &&
                          b_longest <= 64 && (flags & ~SDRB_FLAG_SWAP) == 0;
         // ande of dense rows has a bound far above its result: only the estimate-sized call pays there

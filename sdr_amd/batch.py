@@ -346,6 +346,13 @@ class SDRBatch:
             data_t.data_ptr() if (unit and self.nnz) else None, _stream_handle(self.device, stream)))
         return wire
 
+    def table_width(self) -> int:
+        """The width the table kernels index this batch by: the declared one, or largest id + 1 for rows uploaded
+        without a declared width and without a negative id; 0 when there is none."""
+        w = C.c_int32()
+        check(self._lib.sdrb_batch_table_width(self._h, C.byref(w)))
+        return int(w.value)
+
     def stats(self) -> dict:
         """Shape and id statistics of the uploaded batch (what a zero-copy view needs)."""
         lo, hi = C.c_int32(), C.c_int32()
@@ -549,12 +556,13 @@ class SDRBatch:
             chunked = self._elem_op_chunked(op, other, swap, stream, algo, flags)
             if chunked is not None:
                 return chunked
+        table_width = other.table_width() if (op == OP_AND and not rowwise and algo is None and pairs and self.n_rows <= 32) else 0
         if (op == OP_AND and not rowwise and algo is None and self.id_bits == 32 and other.id_bits == 32 and pairs
-                and self.n_rows <= 32 and 0 < other.width <= 4096 and other.max_row_len <= 64
+                and self.n_rows <= 32 and 0 < table_width <= 4096 and other.max_row_len <= 64
                 and self.data_kind != DATA_ARITH and other.data_kind != DATA_ARITH):
             # One query, or a handful, against a database: offsets and elements in one enqueue, the element buffers
             # sized by the expected number of matches (ids spread evenly over the width) with room to spare.
-            expected = self.nnz * other.nnz / other.width
+            expected = self.nnz * other.nnz / table_width
             cap = int(min(min(self.nnz * other.n_rows, other.nnz * self.n_rows), expected * 1.3 + 8.0 * expected ** 0.5 + 4096))
             has_data = this_kind != DATA_EMPTY
 

@@ -502,6 +502,15 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
     return SDRB_OK;
 }
 
+int sdrb_batch_table_width(const sdrb_batch* batch, int32_t* width) {
+    if (!batch || !width) {
+        set_error("sdrb_batch_table_width: null argument");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    *width = batch->id_bits == 32 ? batch->width : (batch->narrow ? batch->narrow->width : 0);
+    return SDRB_OK;
+}
+
 int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id) {
     if (!batch) {
         set_error("null batch handle");

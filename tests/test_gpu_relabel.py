@@ -115,6 +115,7 @@ def test_undeclared_width_is_derived_from_the_ids_whatever_their_size():
         ts, as_ = Batch(t.off, (t.ids.astype(np.int64) * factor).astype(np.int32), t.data), Batch(a.off, (a.ids.astype(np.int64) * factor).astype(np.int32), a.data)
         dt, da = SDRBatch.from_csr(ts.off, ts.ids, ts.data), SDRBatch.from_csr(as_.off, as_.ids, as_.data)
         assert dt.width == 0 and da.width == 0          # what callers see stays "undeclared"
+        assert da.table_width() == int(as_.ids.max()) + 1
         for op in (AND, OR, XOR, RM):
             assert np.array_equal(sizes(op, dt, da), oracle.port().size_op(op, ts, as_)), (NAMES[op], factor)
         for name, op in (("ande", AND), ("ore", OR), ("rme", RM)):
@@ -122,6 +123,15 @@ def test_undeclared_width_is_derived_from_the_ids_whatever_their_size():
             w_off, w_ids, w_data = oracle.port().elem_op(op, ts, as_)
             assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids), (name, factor)
             assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), (name, factor)
+    # a handful of queries against such a database take the fused few-rows path (total still on the device)
+    few = SDRBatch.from_csr(t.off[:4], t.ids[: int(t.off[3])], t.data[: int(t.off[3])])
+    res = few.ande(SDRBatch.from_csr(a.off, a.ids, a.data))
+    assert res._total_dev is not None
+    w_off, w_ids, w_data = oracle.port().elem_op(AND, Batch(t.off[:4], t.ids[: int(t.off[3])], t.data[: int(t.off[3])]), a)
+    off, ids, data = res.to_host()
+    assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids) and np.array_equal(data.view(np.uint32), w_data.view(np.uint32))
+    neg = SDRBatch.from_csr(a.off, a.ids - 1, a.data)
+    assert neg.table_width() == 0                      # a negative id: no width
     # the table kernels can be asked for by name once a width is derived
     small_t, small_a = SDRBatch.from_csr(t.off, t.ids, None), SDRBatch.from_csr(a.off, a.ids, None)
     assert np.array_equal(sizes(AND, small_t, small_a, algo="bitslice"), oracle.port().size_op(AND, Batch(t.off, t.ids, None), Batch(a.off, a.ids, None)))
