@@ -146,10 +146,16 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
 /*
  * Batches with 64-bit ids (the reference's SDRElem<long, ...>, fuzzed in src/fuzz.cpp:413-423).
  * Such a batch has no declared width and EmptyData or UnitData payloads; it is taken by sdrb_size_op,
- * sdrb_equal, sdrb_elem_op_count and sdrb_elem_op_fill64 (both batches of a call must hold ids of the same
- * width; the per-pair merge kernels serve them).  When every id of a batch fits 32 bits the handle also keeps the
- * ids narrowed; two such batches are served by the kernels of the 32-bit path (ids of results widened back), and
- * sdrb_allpairs_topk takes them as well.  Everything else refuses 64-bit batches.
+ * sdrb_equal, sdrb_elem_op_count / _bound, sdrb_elem_op_fill64 and the visitors (the per-pair merge kernels serve
+ * them).  When every id of a batch fits 32 bits the handle also keeps the ids narrowed; two such batches are served
+ * by the kernels of the 32-bit path (ids of results widened back), and sdrb_allpairs_topk takes them as well.
+ * The two batches of a call may differ in id width, as the fuzzed pairs do (`long` ids against `int` ids): the
+ * 64-bit batch is taken through its narrowed ids when it keeps them, else the 32-bit batch through a widened copy
+ * of its ids made for the call.  A result holds ids of `this`'s width (SDR.hpp:151-152): sdrb_elem_op_fill64 when
+ * `this` is the 64-bit batch, sdrb_elem_op_fill otherwise (refused for ore / xore against 64-bit ids that do not
+ * fit 32 bits, which such a result could not hold).  Ids compare by value; the reference, handed a `long` id beyond
+ * 32 bits in a search over `int` elements, truncates it (SDRElem.hpp:73-75 takes the element's own id type), so
+ * that case has no reference result to match.  Everything else refuses 64-bit batches.
  */
 int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out);
 int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,

@@ -859,13 +859,13 @@ class SDRBatch {
         e.na = rowwise ? 1 : n_rows_;
         e.nb = db.n_rows_;
         e.has_data = self.kind_ != SDRB_DATA_EMPTY;
-        e.id_bits = id_bits_;
+        e.id_bits = self.id_bits_;   // a result holds ids of `this`'s width (the two batches may differ)
         e.offsets = detail::DeviceBuffer(db.device_, (e.na * e.nb + 1) * sizeof(uint32_t));
         if (!rowwise && id_bits_ == 32 && db.id_bits_ == 32 && elem_op_one_enqueue(op, db, flags, stream, &e)) return e;
         check(sdrb_elem_op_count(h_, db.h_, op, flags, static_cast<uint32_t*>(e.offsets.ptr), &e.total, stream));
-        e.ids = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * (id_bits_ / 8));
+        e.ids = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * (e.id_bits / 8));
         if (e.has_data) e.data = detail::DeviceBuffer(db.device_, (e.total ? e.total : 1) * sizeof(float));
-        if (id_bits_ == 64) {
+        if (e.id_bits == 64) {
             check(sdrb_elem_op_fill64(h_, db.h_, op, flags, static_cast<const uint32_t*>(e.offsets.ptr),
                                       static_cast<int64_t*>(e.ids.ptr), static_cast<float*>(e.data.ptr), stream));
         } else {

@@ -610,9 +610,10 @@ class SDRBatch:
                                            C.byref(total), s))
         n = int(total.value)
         # buffers keep at least one element so an empty result still has a valid pointer
-        ids_buf = torch.empty(max(n, 1), dtype=torch.int64 if self.id_bits == 64 else torch.int32, device=dev)
+        this_bits = other.id_bits if swap else self.id_bits      # a result holds ids of `this`'s width
+        ids_buf = torch.empty(max(n, 1), dtype=torch.int64 if this_bits == 64 else torch.int32, device=dev)
         data_buf = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if this_kind != DATA_EMPTY else None
-        fill = self._lib.sdrb_elem_op_fill64 if self.id_bits == 64 else self._lib.sdrb_elem_op_fill
+        fill = self._lib.sdrb_elem_op_fill64 if this_bits == 64 else self._lib.sdrb_elem_op_fill
         check(fill(self._h, other._h, op, flags, offsets.data_ptr(),
                                           ids_buf.data_ptr(),
                                           data_buf.data_ptr() if data_buf is not None else None, s))

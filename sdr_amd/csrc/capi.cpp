@@ -175,7 +175,7 @@ bool id_only(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap) {
     return op == SDRB_OP_OR || self->data_kind == SDRB_DATA_EMPTY;
 }
 
-int check_pair(const sdrb_batch* a, const sdrb_batch* b, int op) {
+int check_pair(const sdrb_batch* a, const sdrb_batch* b, int op, bool widths_may_differ = false) {
     if (!a || !b) {
         set_error("null batch handle");
         return SDRB_ERR_INVALID_ARG;
@@ -192,7 +192,7 @@ int check_pair(const sdrb_batch* a, const sdrb_batch* b, int op) {
         set_error("batch has no uploaded rows");
         return SDRB_ERR_INVALID_ARG;
     }
-    if (a->id_bits != b->id_bits) {
+    if (a->id_bits != b->id_bits && !widths_may_differ) {
         set_error("one batch holds 32-bit ids and the other 64-bit ids");
         return SDRB_ERR_INVALID_ARG;
     }
@@ -216,6 +216,56 @@ bool narrow_pair(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags) {
     a = a->narrow;
     b = b->narrow;
     return true;
+}
+
+// Batches whose ids differ in width.  The reference mixes them freely -- its fuzzer runs SDRElem<long, ...> rows against
+// SDRElem<int, ...> rows (src/fuzz.cpp:413-423) and ids compare by value (SDRElem.hpp:56-75).  Here the 64-bit batch is
+// taken through its 32-bit twin when it keeps one (every kernel of the 32-bit path then applies); when its ids do not
+// fit 32 bits, the 32-bit batch is taken through a widened copy of its ids (scratch of the call's stream) and the pair
+// runs on the 64-bit kernels.  Batches of equal width: narrow_pair.  After the call both pointers name batches of one
+// width; `h` keeps the widened view alive for the call.
+struct IdHarmony {
+    sdrb_batch wide;
+};
+int harmonise_ids(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags, hipStream_t s, IdHarmony* h) {
+    if (!a || !b) return SDRB_OK;   // the checks that follow name the null handle
+    if (a->id_bits == b->id_bits) {
+        narrow_pair(a, b, flags);
+        return SDRB_OK;
+    }
+    const sdrb_batch*& wide = a->id_bits == 64 ? a : b;
+    const sdrb_batch*& slim = a->id_bits == 64 ? b : a;
+    if (wide->narrow) {
+        wide = wide->narrow;
+        return SDRB_OK;
+    }
+    if (a->device != b->device || !slim->d_offsets) return SDRB_OK;   // check_pair reports these
+    h->wide = *slim;
+    sdrb_batch& v = h->wide;
+    v.id_bits = 64;
+    v.width = 0;
+    v.width_declared = false;
+    v.owns_storage = false;
+    v.narrow = nullptr;
+    v.d_narrow_ids = nullptr;
+    v.derived_home = nullptr;
+    v.d_bitplanes = nullptr;
+    v.d_dense8 = nullptr;
+    v.bitplanes_ready = v.dense_ready = nullptr;
+    if (slim->nnz) {
+        DeviceGuard guard(slim->device);
+        if (!guard.ok) {
+            set_error("hipSetDevice(%d) failed", slim->device);
+            return SDRB_ERR_HIP;
+        }
+        int64_t* ids64 = static_cast<int64_t*>(workspace(slim->device, s, 14, (size_t)slim->nnz * sizeof(int64_t)));
+        if (!ids64) return SDRB_ERR_HIP;
+        const int rc = launch_widen_ids(slim->d_ids, ids64, slim->nnz, s);
+        if (rc != SDRB_OK) return rc;
+        v.d_ids = reinterpret_cast<int32_t*>(ids64);
+    }
+    slim = &h->wide;
+    return SDRB_OK;
 }
 
 // Which payload pairings the set algebra takes: EmptyData and UnitData in any mix (UnitData.hpp:43-46),
@@ -567,8 +617,9 @@ int sdrb_batch_destroy(sdrb_batch* batch) {
 int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint32_t* out,
                  uint64_t ld_out, void* stream) {
     TraceRange range("sdrb_size_op");
-    narrow_pair(a, b, flags);
-    int rc = check_pair(a, b, op);
+    IdHarmony harmony;
+    int rc = harmonise_ids(a, b, flags, static_cast<hipStream_t>(stream), &harmony);
+    if (rc == SDRB_OK) rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, op);
     if (rc != SDRB_OK) return rc;
     const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
@@ -759,8 +810,9 @@ int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
 
 int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream) {
     TraceRange range("sdrb_equal");
-    narrow_pair(a, b, flags);
-    int rc = check_pair(a, b, SDRB_OP_AND);
+    IdHarmony harmony;
+    int rc = harmonise_ids(a, b, flags, static_cast<hipStream_t>(stream), &harmony);
+    if (rc == SDRB_OK) rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
     if (rc != SDRB_OK) return rc;
     if (!has_payload(a) && has_payload(b)) {
@@ -1049,9 +1101,10 @@ uint64_t elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags,
                        uint32_t* out_offsets, uint64_t* total, void* stream) {
     TraceRange range("sdrb_elem_op_count");
-    narrow_pair(a, b, flags);
+    IdHarmony harmony;
     uint64_t pairs = 0;
-    int rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
+    int rc = harmonise_ids(a, b, flags, static_cast<hipStream_t>(stream), &harmony);
+    if (rc == SDRB_OK) rc = check_count_call(a, b, op, flags, out_offsets, &pairs);
     if (rc != SDRB_OK) return rc;
     if (!total) {
         set_error("sdrb_elem_op_count: null output");
@@ -1072,7 +1125,7 @@ int sdrb_elem_op_count(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 }
 
 int sdrb_elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, uint64_t* bound) {
-    int rc = check_pair(a, b, op);
+    int rc = check_pair(a, b, op, true);   // shapes only: the ids' widths may differ
     if (rc != SDRB_OK) return rc;
     if (!bound) {
         set_error("sdrb_elem_op_bound: null output");
@@ -1085,10 +1138,25 @@ int sdrb_elem_op_bound(const sdrb_batch* a, const sdrb_batch* b, int op, unsigne
 namespace {
 int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, const uint32_t* out_offsets,
                      void* out_ids_any, int want_bits, float* out_data, void* stream) {
-    if (want_bits == 64 && out_offsets && out_ids_any) {
+    // The result's ids are `this`'s (SDR.hpp:151-152: ret_t defaults to this's element type); the pair itself may run
+    // on ids of the other width (harmonise_ids): then the fill goes through scratch and the ids are converted.
+    IdHarmony harmony;
+    if (a && b && out_offsets && out_ids_any) {
+        const sdrb_batch* self0 = (flags & SDRB_FLAG_SWAP) ? b : a;
+        if (self0->id_bits != want_bits) {
+            set_error("the result takes the ids of `this`, which are %d-bit: use %s", self0->id_bits,
+                      self0->id_bits == 64 ? "sdrb_elem_op_fill64" : "sdrb_elem_op_fill");
+            return SDRB_ERR_INVALID_ARG;
+        }
+        hipStream_t s = static_cast<hipStream_t>(stream);
         const sdrb_batch *na = a, *nb = b;
-        if (narrow_pair(na, nb, flags)) {
-            // both batches keep 32-bit twins: fill through the 32-bit kernels into scratch, then widen the ids
+        const int hrc = harmonise_ids(na, nb, flags, s, &harmony);
+        if (hrc != SDRB_OK) return hrc;
+        if (na->id_bits == nb->id_bits && na->id_bits != want_bits) {
+            if (want_bits == 32 && (op == SDRB_OP_OR || op == SDRB_OP_XOR)) {
+                set_error("a union of 32-bit `this` rows with 64-bit ids that do not fit 32 bits has no 32-bit result");
+                return SDRB_ERR_UNSUPPORTED;
+            }
             const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
             const uint64_t pairs = rowwise ? nb->n_rows : na->n_rows * nb->n_rows;
             DeviceGuard guard(nb->device);
@@ -1096,16 +1164,24 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
                 set_error("hipSetDevice(%d) failed", nb->device);
                 return SDRB_ERR_HIP;
             }
-            hipStream_t s = static_cast<hipStream_t>(stream);
             uint32_t total = 0;
             SDRB_HIP(hipMemcpyAsync(&total, out_offsets + pairs, sizeof total, hipMemcpyDeviceToHost, s));
             SDRB_HIP(hipStreamSynchronize(s));
             if (total == 0) return SDRB_OK;
-            int32_t* tmp = static_cast<int32_t*>(workspace(nb->device, s, 11, (size_t)total * sizeof(int32_t)));
+            const size_t each = want_bits == 64 ? sizeof(int32_t) : sizeof(int64_t);
+            void* tmp = workspace(nb->device, s, 11, (size_t)total * each);
             if (!tmp) return SDRB_ERR_HIP;
-            const int rc32 = elem_op_fill_any(na, nb, op, flags, out_offsets, tmp, 32, out_data, stream);
-            if (rc32 != SDRB_OK) return rc32;
-            return launch_widen_ids(tmp, static_cast<int64_t*>(out_ids_any), total, s);
+            const int rc_inner = elem_op_fill_any(na, nb, op, flags, out_offsets, tmp, na->id_bits, out_data, stream);
+            if (rc_inner != SDRB_OK) return rc_inner;
+            if (want_bits == 64) return launch_widen_ids(static_cast<const int32_t*>(tmp), static_cast<int64_t*>(out_ids_any), total, s);
+            // intersections and differences of 32-bit `this` rows hold ids of `this` only: they narrow exactly
+            return launch_narrow_ids(static_cast<const int64_t*>(tmp), static_cast<int32_t*>(out_ids_any), total, s);
+        }
+        a = na;
+        b = nb;
+        if (a->id_bits != want_bits) {   // (widths still differ only when a check below refuses the pair)
+            set_error("these batches hold %d-bit ids", a->id_bits);
+            return SDRB_ERR_INVALID_ARG;
         }
     }
     int rc = check_pair(a, b, op);
@@ -1284,7 +1360,9 @@ int check_visit(const sdrb_batch* a, const sdrb_batch* b, int which) {
 int sdrb_visit_count(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, uint32_t* out_offsets,
                      uint64_t* total, void* stream) {
     TraceRange range("sdrb_visit_count");
-    const int rc = check_visit(a, b, which);
+    IdHarmony harmony;
+    int rc = check_visit(a, b, which);
+    if (rc == SDRB_OK) rc = harmonise_ids(a, b, flags, static_cast<hipStream_t>(stream), &harmony);
     if (rc != SDRB_OK) return rc;
     IdView va(a), vb(b);
     // the number of callbacks is the size of the id-only intersection / union
@@ -1295,8 +1373,10 @@ int sdrb_visit_count(const sdrb_batch* a, const sdrb_batch* b, int which, unsign
 int sdrb_visit_fill(const sdrb_batch* a, const sdrb_batch* b, int which, unsigned flags, const uint32_t* out_offsets,
                     uint32_t* this_pos, uint32_t* arg_pos, void* stream) {
     TraceRange range("sdrb_visit_fill");
+    IdHarmony harmony;
     int rc = check_visit(a, b, which);
     const int op = which == SDRB_VISIT_AND ? SDRB_OP_AND : SDRB_OP_OR;
+    if (rc == SDRB_OK) rc = harmonise_ids(a, b, flags, static_cast<hipStream_t>(stream), &harmony);
     if (rc == SDRB_OK) rc = check_pair(a, b, op);
     if (rc != SDRB_OK) return rc;
     if (a->n_rows == 0 || b->n_rows == 0) return SDRB_OK;

@@ -427,6 +427,19 @@ __global__ __launch_bounds__(256) void k_widen_ids(const int32_t* __restrict__ i
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) out[k] = (int64_t)in[k];
 }
 
+__global__ __launch_bounds__(256) void k_narrow_result_ids(const int64_t* __restrict__ in, int32_t* __restrict__ out, uint64_t n) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) out[k] = (int32_t)in[k];
+}
+
+// ids known to fit 32 bits (elements of a 32-bit `this` that ran through the 64-bit kernels)
+int launch_narrow_ids(const int64_t* in, int32_t* out, uint64_t n, hipStream_t stream) {
+    if (n == 0) return SDRB_OK;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_narrow_result_ids, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, in, out, n);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
 int launch_widen_ids(const int32_t* in, int64_t* out, uint64_t n, hipStream_t stream) {
     if (n == 0) return SDRB_OK;
     const uint64_t blocks = (n + 255) / 256;

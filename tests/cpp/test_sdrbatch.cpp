@@ -23,6 +23,9 @@ using namespace sparse_distributed_representation;
 static long g_checks = 0;
 #define REQUIRE(x) do { ++g_checks; if (!(x)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
 
+// long ids are spread beyond 32 bits unless `small_long` keeps them as they are (ids that 32 bits would hold too)
+static bool g_small_long = false;
+
 template <typename SDR_t>
 std::vector<SDR_t> make_rows(std::mt19937& rng, size_t n, int width, int max_len) {
     using Elem = typename SDR_t::value_type;
@@ -33,12 +36,20 @@ std::vector<SDR_t> make_rows(std::mt19937& rng, size_t n, int width, int max_len
     std::normal_distribution<float> gauss(0.0f, 3.0f);
     for (auto& r : rows) {
         int len = (int)(rng() % (unsigned)(max_len + 1));
-        std::set<int> ids;
-        while ((int)ids.size() < len) ids.insert((int)(rng() % (unsigned)width));
-        std::vector<Elem> elems;
-        for (int small : ids) {
+        std::set<int> drawn;
+        while ((int)drawn.size() < len) drawn.insert((int)(rng() % (unsigned)width));
+        std::set<Id> ids;
+        for (int small : drawn) {
             Id id = small;
-            if constexpr (sizeof(Id) > 4) id = (Id)small * 0x100000003L - 0x4000000000L;   // ids that need 64 bits, order kept
+            if constexpr (sizeof(Id) > 4) {
+                // ids that need 64 bits, of either sign; every third id stays small, so that rows of `int` ids can share it
+                if (!g_small_long && small % 3 == 1) id = (Id)small * 0x100000003L + 0x4000000000L;
+                if (!g_small_long && small % 3 == 2) id = -(Id)small * 0x100000003L - 0x4000000000L;
+            }
+            ids.insert(id);
+        }
+        std::vector<Elem> elems;
+        for (Id id : ids) {
             if constexpr (std::is_same_v<Data, UnitData>) elems.push_back(Elem(id, UnitData(val(rng))));
             else if constexpr (std::is_same_v<Data, ArithData<float>>) elems.push_back(Elem(id, ArithData<float>(gauss(rng))));
             else elems.push_back(Elem(id));
@@ -571,6 +582,15 @@ int main() {
         if (run<SDR<LE>, SDR<LE>>("long ids", rng, 512, 0)) return 1;
         if (run<SDR<LU>, SDR<LU>>("long ids, unit x unit", rng, 200, 0)) return 1;
         if (run<SDR<LU>, SDR<LE>>("long ids, unit x empty", rng, 200, 0)) return 1;
+        // ids of different widths in one call, the pairing the reference's fuzzer runs (src/fuzz.cpp:413-423)
+        g_small_long = true;
+        if (run<SDR<LU>, SDR<U>>("long x int ids (all fit)", rng, 200, 0)) return 1;
+        if (run<SDR<U>, SDR<LU>>("int x long ids (all fit)", rng, 200, 0)) return 1;
+        if (run<SDR<LE>, SDR<E>>("long x int ids, empty", rng, 512, 0)) return 1;
+        if (run<SDR<LE>, SDR<U>>("long x int ids, e x u", rng, 200, 0)) return 1;
+        // (long ids BEYOND 32 bits against int ids are not compared here: the reference's search hands the long id to
+        // SDRElem<int>::operator<(int), SDRElem.hpp:73-75, which truncates it; the engine compares ids by value)
+        g_small_long = false;
         if (run_few<SDR<E>>("few rows, ande", rng, 512, 40, false)) return 1;
         if (run_few<SDR<U>>("few rows, ande, unit", rng, 300, 40, false)) return 1;
         if (run_few<SDR<U>>("few rows, ande, refill", rng, 64, 40, true)) return 1;

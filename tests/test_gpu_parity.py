@@ -622,13 +622,75 @@ def test_64_bit_batches_are_refused_where_not_supported():
     off, ids, _ = util.ragged_rows(rng, 20, 100, 10)
     wide = SDRBatch.from_csr(off, ids.astype(np.int64) * (1 << 35))
     narrow = SDRBatch.from_csr(off, ids)
-    for call in (lambda: wide.ands(narrow), lambda: wide.allpairs_topk(wide, 4), lambda: wide.range_size([0], [5]),
-                 lambda: wide.to_wire()):
+    for call in (lambda: wide.allpairs_topk(wide, 4), lambda: wide.range_size([0], [5]), lambda: wide.to_wire()):
         with pytest.raises(sdr_amd.SdrbError):
             call()
     with pytest.raises(sdr_amd.SdrbError) as e:
         SDRBatch.from_csr(np.array([0, 2], np.uint64), np.array([5, 5], np.int64))
     assert e.value.code == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PAIRINGS))
+def test_batches_whose_ids_differ_in_width(name):
+    """`long` ids against `int` ids, what the reference's fuzzer runs (src/fuzz.cpp:413-423: SDRElem<long, UnitData> rows
+    against SDRElem<int, UnitData> rows).  (1) long ids that fit 32 bits: the twin serves the pair; (2) long ids beyond
+    32 bits: the 32-bit batch is widened for the call.  A result holds ids of `this`'s width."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(41 + 2 * tu + au)
+    t = Batch(*util.ragged_rows(rng, 33, 3000, 40, tu))
+    a = Batch(*util.ragged_rows(rng, 400, 3000, 40, au))
+    t64, t32 = SDRBatch.from_csr(t.off, t.ids.astype(np.int64), t.data), SDRBatch.from_csr(t.off, t.ids, t.data)
+    a64, a32 = SDRBatch.from_csr(a.off, a.ids.astype(np.int64), a.data), SDRBatch.from_csr(a.off, a.ids, a.data)
+    for dt, da, id_type in ((t64, a32, np.int64), (t32, a64, np.int32)):
+        for op in range(4):
+            assert np.array_equal(gpu_sizes(op, dt, da), oracle.port().size_op(op, t, a)), op
+            assert np.array_equal(gpu_sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), op
+            off, ids, data = gpu_elems(op, dt, da)
+            w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+            assert ids.dtype == id_type
+            assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids.astype(id_type)), op
+            assert (data is None) == (w_data is None) and (data is None or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))
+        if tu or not au:    # (an EmptyData `this` compares with EmptyData rows only)
+            assert np.array_equal(dt.equals(da).cpu().numpy().view(np.uint32), oracle.port().equal(t, a))
+        for which, vname in ((0, "andv"), (1, "orv")):
+            off, tp, ap = getattr(dt, vname)(da).to_host()
+            w_off, w_tp, w_ap = oracle.port().visit(which, t, a)
+            assert np.array_equal(off, w_off) and np.array_equal(tp, w_tp) and np.array_equal(ap, w_ap), vname
+
+    # (2) every odd id of `this` moved beyond 32 bits (the rows stay ascending: the moved ids are larger than all
+    # others); in the oracle's 32-bit model the same ids are moved by 100000, which keeps every comparison
+    def moved(b, by):
+        ids = b.ids.astype(np.int64)
+        rows = [np.sort(np.where(r % 2 == 1, r + by, r)) for r in np.split(ids, b.off[1:-1].astype(np.int64))]
+        order = [np.argsort(np.where(r % 2 == 1, r + by, r), kind="stable") for r in np.split(ids, b.off[1:-1].astype(np.int64))]
+        data = None if b.data is None else np.concatenate([d[o] for d, o in zip(np.split(b.data, b.off[1:-1].astype(np.int64)), order)])
+        return np.concatenate(rows), data
+    far_ids, far_data = moved(t, np.int64(1) << 40)
+    model_ids, model_data = moved(t, np.int64(100000))
+    far = SDRBatch.from_csr(t.off, far_ids, far_data)
+    model = Batch(t.off, model_ids.astype(np.int32), model_data)
+    assert far.id_bits == 64
+    for op in range(4):
+        assert np.array_equal(gpu_sizes(op, far, a32), oracle.port().size_op(op, model, a)), op
+        assert np.array_equal(gpu_sizes(op, a32, far), oracle.port().size_op(op, a, model)), op
+        # `this` = the 64-bit batch: ids of the result are 64-bit
+        off, ids, data = gpu_elems(op, far, a32)
+        w_off, w_ids, w_data = oracle.port().elem_op(op, model, a)
+        w_ids = w_ids.astype(np.int64)
+        w_ids = np.where(w_ids >= 100000, w_ids - 100000 + (np.int64(1) << 40), w_ids)
+        assert ids.dtype == np.int64 and np.array_equal(off, w_off) and np.array_equal(ids, w_ids), op
+        assert (data is None) == (w_data is None) and (data is None or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))
+        # `this` = the 32-bit batch: intersections and differences hold its ids; unions cannot
+        if op in (AND, RM):
+            off, ids, data = gpu_elems(op, a32, far)
+            w_off, w_ids, w_data = oracle.port().elem_op(op, a, model)
+            assert ids.dtype == np.int32 and np.array_equal(off, w_off) and np.array_equal(ids, w_ids), op
+            assert (data is None) == (w_data is None) and (data is None or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))
+        else:
+            with pytest.raises(sdr_amd.SdrbError) as e:
+                gpu_elems(op, a32, far)
+            assert e.value.code == -5
 
 
 def test_lanemerge_fill_signed_ids_chunks_of_a_and_sentinel():

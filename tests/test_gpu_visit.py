@@ -151,8 +151,9 @@ def test_empty_rows_and_batches():
     assert (tp == POS_NONE).all() and ap.tolist() == [0, 1, 0, 1, 2] * 3
     with pytest.raises(ValueError):
         some.andv(SDRBatch.from_rows([[1]], width=64), rowwise=True)
-    with pytest.raises(sdr_amd.SdrbError):          # batches of different id widths
-        some.andv(SDRBatch.from_csr(np.array([0, 1], np.uint64), np.array([1], np.int64), None))
+    # batches of different id widths visit each other like any two rows: id 1 of [1, 5] and of [0, 1, 63]
+    off, tp, ap = some.andv(SDRBatch.from_csr(np.array([0, 1], np.uint64), np.array([1], np.int64), None)).to_host()
+    assert off.tolist() == [0, 1, 1, 2] and tp.tolist() == [0, 1] and ap.tolist() == [0, 0]
 
 
 def test_andv_over_sub_ranges():
