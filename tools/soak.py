@@ -145,6 +145,26 @@ def main():
                 print("MISMATCH 64-bit ids", SIZE[op], tag, flush=True)
                 return 1
             checks += 2
+            # ids of different widths in one call (`long` this, `int` arg and the other way round)
+            a32 = SDRBatch.from_csr(a.off, a.ids, a.data)
+            t32 = SDRBatch.from_csr(t.off, t.ids, t.data)
+            for this_b, arg_b, id_type in ((t64, a32, np.int64), (t32, a64, np.int32)):
+                got = getattr(this_b, SIZE[op])(arg_b).cpu().numpy().view(np.uint32)
+                off, ids, data = getattr(this_b, ELEM[op])(arg_b).to_host()
+                # (the 32-bit batch holds the plain ids: compare through the oracle on matching id spaces)
+                if id_type == np.int64:
+                    want_s = oracle.port().size_op(op, Batch(t.off, (t.ids.astype(np.int64) * 3 - 5).astype(np.int32), t.data), a)
+                    w2 = oracle.port().elem_op(op, Batch(t.off, (t.ids.astype(np.int64) * 3 - 5).astype(np.int32), t.data), a)
+                else:
+                    want_s = oracle.port().size_op(op, t, Batch(a.off, (a.ids.astype(np.int64) * 3 - 5).astype(np.int32), a.data))
+                    w2 = oracle.port().elem_op(op, t, Batch(a.off, (a.ids.astype(np.int64) * 3 - 5).astype(np.int32), a.data))
+                ok = np.array_equal(got, want_s) and np.array_equal(off, w2[0]) and ids.dtype == id_type and \
+                    np.array_equal(ids, w2[1].astype(id_type)) and \
+                    ((data is None and w2[2] is None) or np.array_equal(data.view(np.uint32), w2[2].view(np.uint32)))
+                if not ok:
+                    print("MISMATCH mixed id widths", SIZE[op], id_type, tag, flush=True)
+                    return 1
+                checks += 2
             # ids no table can index: 32-bit ids spread over the whole signed range, 64-bit ids beyond 32 bits
             # (both keep the rows' order); sizes only depend on which ids rows share
             if len_a and len_b and width <= 4096:
