@@ -40,19 +40,32 @@ void* g_static_ptr[kMaxDevices];   // device address of `scratch` on each device
 // OUTB = 4: a lane stores the uint32 count of its row of B for one row of A per instruction (256 B per wave and row).
 // OUTB = 1 / 2 (counts as bytes / 16-bit words): the four lanes of a quad first exchange their registers -- a 4 x 4
 // byte transpose in two steps of a DPP move and a byte permute -- so that a lane holds the counts of ONE row of A for
-// the quad's four neighbouring rows of B and stores them as one dword (two for 16-bit counts): a wave instruction
-// then writes 64 (128) contiguous bytes to each of four rows of A, a quarter of the store instructions for a quarter
-// (half) of the bytes.  `narrow` carries what the narrow forms need per lane (see NarrowLane).
+// the quad's four neighbouring rows of B as one dword (two for 16-bit counts); these go into a stage in LDS, and
+// the block's waves carry the stage out a whole row piece (256 or 512 contiguous bytes) per instruction: a quarter
+// of the store instructions for a quarter (half) of the bytes.  `narrow` carries what the narrow forms need per lane
+// (see NarrowLane).
+// rows of the LDS stage are a little longer than their 256 counts (4 bytes; 8 for 16-bit counts, whose accesses are
+// 8 bytes wide): the four rows a quad writes then start in different banks
+template <int OUTB>
+constexpr uint32_t kStageStride = 256u * OUTB + 4u * OUTB;
+template <int OUTB>
+constexpr int kNarrowStages = OUTB == 1 ? 2 : 1;
+
 struct NarrowLane {
     uint32_t sel_a, sel_b;     // byte selectors of the two transpose steps for this lane of its quad
-    uint32_t row_in_quad;      // lane & 3: which of the four rows r, r+8, r+16, r+24 the lane stores
+    uint32_t row_in_quad;      // lane & 3: which of the four rows r, r+8, r+16, r+24 the lane holds after the transpose
     uint32_t lb_lo, lb_hi;     // |B_j| of the quad's four rows of B, packed as bytes (lb_lo) or 16-bit pairs (lb_lo, lb_hi)
-    uint32_t voff;             // byte offset of the lane's store inside a row group: row_in_quad * 8 rows + its columns;
-                               // 0xF0000000 (past every buffer size, which end below 0xC8000000) when the quad's rows of B do not exist
+    uint32_t voff;             // without a stage: byte offset of the lane's store inside a row group (row_in_quad * 8 rows + its
+                               // columns); 0xF0000000 (past every buffer size, which end below 0xC8000000) when the quad's
+                               // rows of B do not exist
+    unsigned char* stage;      // the block's stage in LDS
+    uint32_t stage_col;        // byte offset of the quad's four columns inside a stage row
+    uint32_t lane_col;         // byte offset of the lane's piece of a row on the way out (stage row and output row alike)
+    uint32_t wave;             // the lane's wave in the block (uniform)
     uint32_t cols_bytes;       // bytes of a row of the output that this block's rows of B cover, whole quads (uniform)
 };
 
-template <int NCH, int MODE, int OUTB>
+template <int NCH, int MODE, int OUTB, bool STAGED>
 __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[8 * NCH],
                                           uint32_t rows_in_tile, uint32_t la_vec, uint32_t lbterm,
                                           char* tile_out, uint64_t row_bytes, uint32_t nrec, uint32_t voff,
@@ -91,7 +104,9 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] <<= SH;
         }
-        if constexpr (OUTB != 4) {
+        if constexpr (OUTB != 4 && !STAGED) {
+            // (tables of 4096 words leave no room for a stage beside two resident blocks: straight from the registers,
+            // four rows a store instruction)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 // transpose inside the quad: afterwards this lane holds row (32 h + r + 8 * row_in_quad) of A for the
@@ -135,6 +150,63 @@ __device__ __forceinline__ void tile_body(const u64* buf, const uint32_t (&off)[
             row_ptr += 32 * row_bytes;
             continue;
         }
+        if constexpr (OUTB != 4) {
+            // The half tile goes through a stage in LDS -- 32 rows of A by the block's 256 columns -- and leaves it a
+            // whole row piece per wave instruction (256 bytes of byte counts, 512 of 16-bit counts): as four pieces of a
+            // quarter of that per instruction, straight from the registers, the same matrix streams a fifth slower
+            // (pure stores: 4.8 against 5.9 TB/s for 16-bit counts).  Byte counts alternate between two stages, so
+            // that the second half's writes need not wait for the first half's reads; 16-bit counts share one.
+            constexpr uint32_t kStride = kStageStride<OUTB>;
+            unsigned char* stage_h = narrow.stage + (kNarrowStages<OUTB> == 2 ? h * 32u * kStride : 0u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                // transpose inside the quad: afterwards this lane holds row (32 h + r + 8 * row_in_quad) of A for the
+                // quad's four rows of B, one count per byte
+                const uint32_t x = acc[r];
+                const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                const uint32_t t = __builtin_amdgcn_perm(y, x, narrow.sel_a);
+                const uint32_t z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, false);   // lane ^ 2
+                uint32_t u = __builtin_amdgcn_perm(z, t, narrow.sel_b);
+                const uint32_t q = 32u * h + r + 8u * narrow.row_in_quad;
+                uint32_t la = 0;
+                if constexpr (MODE != 0) la = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q * 4u), (int)la_vec);
+                unsigned char* slot = stage_h + (r + 8u * narrow.row_in_quad) * kStride + narrow.stage_col;
+                if constexpr (OUTB == 1) {
+                    if constexpr (MODE != 0) u = la * 0x01010101u + narrow.lb_lo - u;
+                    *reinterpret_cast<uint32_t*>(slot) = u;
+                } else {
+                    // bytes 0, 1 and 2, 3 widened to 16-bit pairs: one byte permute each (selector 0x0c yields a zero byte)
+                    uint32_t lo2 = __builtin_amdgcn_perm(0u, u, 0x0c010c00u), hi2 = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
+                    if constexpr (MODE != 0) {
+                        lo2 = la * 0x00010001u + narrow.lb_lo - lo2;
+                        hi2 = la * 0x00010001u + narrow.lb_hi - hi2;
+                    }
+                    *reinterpret_cast<uint2*>(slot) = make_uint2(lo2, hi2);
+                }
+            }
+            __syncthreads();
+            // wave w carries rows w, w + 4, ... of the half out.  Stores are unconditional (a branch around them would
+            // make every later wait for a load -- the next tile of the table -- a wait for all stores before it): rows
+            // past the tile's last get an empty buffer, columns past the block's rows of B lie beyond the buffer's size.
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t row = narrow.wave + 4u * (uint32_t)k;     // uniform
+                const uint32_t size = 32u * h + row < rows_in_tile ? narrow.cols_bytes : 0u;
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(row_ptr + (uint64_t)row * row_bytes, 0, (int)size, 0x00020000);
+                const unsigned char* from = stage_h + row * kStride + narrow.lane_col;
+                if constexpr (OUTB == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t*>(from), rsrc, (int)narrow.lane_col, 0, 0);
+                } else {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const uint2 v = *reinterpret_cast<const uint2*>(from);
+                    const u32x2 both = {v.x, v.y};
+                    __builtin_amdgcn_raw_buffer_store_b64(both, rsrc, (int)narrow.lane_col, 0, 0);
+                }
+            }
+            if constexpr (kNarrowStages<OUTB> == 1) __syncthreads();   // the other half writes the same stage
+            row_ptr += 32 * row_bytes;
+            continue;
+        }
 #pragma unroll
         for (int qq = 0; qq < 32; ++qq) {
             const int q = 32 * h + qq;
@@ -171,6 +243,7 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? (OUTB == 4 ? kMinWaves : SDR
     constexpr int BUF = WCAP + 2;          // words per LDS buffer (zero sentinel at [WCAP])
     constexpr int PF = WCAP / 2 / kBlock;  // uint4 table loads per thread per tile
     __shared__ __attribute__((aligned(16))) u64 lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_lds[OUTB == 4 || WCAP > 2048 ? 16 : kNarrowStages<OUTB> * 32 * kStageStride<OUTB>];
 
     const uint32_t tid = threadIdx.x;
     const uint64_t j0 = (uint64_t)blockIdx.x * kBlock;
@@ -240,6 +313,10 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? (OUTB == 4 ? kMinWaves : SDR
             narrow.lb_hi = l2 | (l3 << 16);
         }
         narrow.voff = (uint64_t)(tid & ~3u) < rows_here ? (uint32_t)((tid & 3) * 8u * row_bytes) + (tid & ~3u) * OUTB : 0xF0000000u;
+        narrow.stage = stage_lds;
+        narrow.stage_col = (tid >> 2) * 4u * OUTB;
+        narrow.lane_col = (tid & 63u) * 4u * OUTB;
+        narrow.wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
         narrow.cols_bytes = (((uint32_t)rows_here + 3u) & ~3u) * OUTB;
     }
 
@@ -255,10 +332,10 @@ __global__ __launch_bounds__(kBlock, WCAP <= 2048 ? (OUTB == 4 ? kMinWaves : SDR
         const uint32_t rows_in_tile = rows_left < (uint32_t)kTileRows ? rows_left : (uint32_t)kTileRows;
         // one straight-line body per LDS buffer so that LDS addresses fold into instruction offsets
         if (((t - t0) & 1) == 0) {
-            tile_body<NCH, MODE, OUTB>(lds, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff, narrow);
+            tile_body<NCH, MODE, OUTB, (WCAP <= 2048)>(lds, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff, narrow);
             if (more) write_tile(pf, lds + BUF, tid);
         } else {
-            tile_body<NCH, MODE, OUTB>(lds + BUF, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff, narrow);
+            tile_body<NCH, MODE, OUTB, (WCAP <= 2048)>(lds + BUF, off, rows_in_tile, la_vec, lbterm, tile_out, row_bytes, nrec, voff, narrow);
             if (more) write_tile(pf, lds, tid);
         }
         __syncthreads();

@@ -117,6 +117,39 @@ __global__ void k_chunked<1>(uint32_t* out, size_t chunk_elems) {
     for (size_t i = threadIdx.x; i < chunk_elems; i += blockDim.x) p[i] = i;
 }
 
+// (n) narrow count matrices: [Q][N] of EB-byte counts (EB = 1 or 2), a block = 256 columns, tiles of 64 rows.
+// QUAD: what the count kernel does -- lane 4g+r stores the four columns 4g..4g+3 of row 8r+b (4 EB bytes), so a wave
+//       instruction writes 64 EB bytes to each of four rows;
+// else: one row per wave instruction, the wave's 64 lanes covering the block's 256 columns of it (4 EB bytes a lane):
+//       what a stage in LDS would make of the same tile -- 256 EB contiguous bytes per instruction.
+template <int EB, bool QUAD>
+__global__ void k_tiles_narrow(unsigned char* out, size_t ld_bytes) {
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* base = out + (size_t)blockIdx.x * 256 * EB;
+    for (int t = 0; t < Q / 64; ++t) {
+        unsigned char* tile = base + (size_t)t * 64 * ld_bytes;
+        if constexpr (QUAD) {
+            const uint32_t r = tid & 3, g4 = tid & ~3u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    unsigned char* p = tile + (size_t)(32 * h + 8 * r + b) * ld_bytes + (size_t)g4 * EB;
+                    if constexpr (EB == 1) *reinterpret_cast<uint32_t*>(p) = (uint32_t)(t + b);
+                    else *reinterpret_cast<v2*>(p) = v2{(uint32_t)t, (uint32_t)b};
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {   // wave w writes rows w, w + 4, ... of the tile
+                unsigned char* p = tile + (size_t)(4 * k + wave) * ld_bytes + (size_t)lane * 4 * EB;
+                if constexpr (EB == 1) *reinterpret_cast<uint32_t*>(p) = (uint32_t)(t + k);
+                else *reinterpret_cast<v2*>(p) = v2{(uint32_t)t, (uint32_t)k};
+            }
+        }
+    }
+}
+
 template <typename F>
 float timeit(F f, int reps = 5) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -152,6 +185,16 @@ int main(int argc, char** argv) {
             snprintf(nm, 64, "chunked x4 grid=%d block=256", g); rep(nm, timeit([&] { k_chunked<4><<<g, 256>>>(out, chunk); })); }
         rep("linear16 grid=8192", timeit([&] { k_linear16<<<8192, 256>>>((uint4*)out, bytes / 16); }));
         rep("tiles RPL1 block=256", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }));
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'n') {   // narrow count matrices: the kernel's quad pattern against whole-row pieces
+        auto rep = [&](const char* name, float ms, size_t b) { printf("%-52s %8.3f ms  %7.1f GB/s\n", name, ms, b / ms / 1e6); fflush(stdout); };
+        unsigned char* o8 = reinterpret_cast<unsigned char*>(out);
+        rep("uint32 tiles RPL1 block=256 (256-B pieces)", timeit([&] { k_tiles<1><<<N / 256, 256>>>(out, N); }), bytes);
+        rep("uint16 quad pattern (4 rows x 128 B an instruction)", timeit([&] { k_tiles_narrow<2, true><<<N / 256, 256>>>(o8, N * 2); }), bytes / 2);
+        rep("uint16 whole rows (512 B of one row an instruction)", timeit([&] { k_tiles_narrow<2, false><<<N / 256, 256>>>(o8, N * 2); }), bytes / 2);
+        rep("uint8 quad pattern (4 rows x 64 B an instruction)", timeit([&] { k_tiles_narrow<1, true><<<N / 256, 256>>>(o8, N); }), bytes / 4);
+        rep("uint8 whole rows (256 B of one row an instruction)", timeit([&] { k_tiles_narrow<1, false><<<N / 256, 256>>>(o8, N); }), bytes / 4);
         return 0;
     }
     if (argc > 1 && argv[1][0] == 'q') {   // only the quad-exchange shapes against the dword tiles
