@@ -243,6 +243,9 @@ __global__ __launch_bounds__(kLrBlock) void k_elem_lanerank(
             const uint32_t run_len = run_end - run_beg;
             const uint32_t span = shift + run_len, quads_out = (span + 3) / 4;
             int32_t* dst = out_ids + (run_beg - shift);    // 16-byte aligned when out_ids is
+#ifdef SDRB_LAB_LANERANK_NO_STORES   // timing only: everything but the run's stores (`aligned` is 0 or 1)
+            if (aligned == 2u)
+#endif
             for (uint32_t c = lane; c < quads_out; c += 64) {
                 const uint2 packed = *reinterpret_cast<const uint2*>(stage + 4 * c);
                 lr_i32x4 v;
