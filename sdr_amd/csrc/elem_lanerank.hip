@@ -34,10 +34,17 @@ namespace sdrb {
 
 namespace {
 
-constexpr int kLrWaves = 2;                  // waves per block (each works on its own 64 rows of B)
+#ifndef SDRB_LR_WAVES
+#define SDRB_LR_WAVES 2
+#endif
+#ifndef SDRB_LR_TABLE_KB
+#define SDRB_LR_TABLE_KB 4   // eight rows of A a block at width 2048: five blocks (ten waves) share a compute unit; with 8 KiB
+                             // four do (config 3, 16 queries: ore 1.37 -> 1.27 ms, rme 1.11 -> 0.97 ms)
+#endif
+constexpr int kLrWaves = SDRB_LR_WAVES;      // waves per block (each works on its own 64 rows of B)
 constexpr int kLrBlock = 64 * kLrWaves;
 constexpr uint32_t kLrRowCap = 64;           // longest row on either side
-constexpr uint32_t kLrTableLds = 8 * 1024;   // LDS for the rank tables of the block's chunk of rows of A
+constexpr uint32_t kLrTableLds = SDRB_LR_TABLE_KB * 1024;   // LDS for the rank tables of the block's chunk of rows of A
 
 typedef uint32_t lr_u32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t lr_i32x4 __attribute__((ext_vector_type(4)));
