@@ -181,6 +181,15 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
 int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id);
 
 /*
+ * Adds `amount` to every id of the batch, in place, on `stream`: SDR::shift (SDR.hpp:1579-1590) and the operators
+ * << >> <<= >>= built on it (SDR.hpp:461-468), for all rows at once.  The reference asserts that no id overflows
+ * (SDR.hpp:1586); here such a shift is refused with SDRB_ERR_ID_RANGE and nothing is changed, and so is one that
+ * takes an id out of a declared width.  Batches of 64-bit ids are shifted while their ids fit 32 bits beforehand
+ * (the id span of others is not kept); rows adopted from caller memory are not modified (SDRB_ERR_UNSUPPORTED).
+ */
+int sdrb_batch_shift(sdrb_batch* batch, int32_t amount, void* stream);
+
+/*
  * The width the table kernels index this batch by: the declared width; for a batch created without one, largest id + 1
  * once rows without a negative id have been uploaded; 0 when there is none (negative ids, 64-bit ids, adopted rows).
  * A caller that sizes buffers by the expected number of matches (sdrb_ande_few) divides by this.

@@ -760,6 +760,34 @@ class SDRBatch {
     SDRBatch& operator+=(const SDRBatch& o) { return ori(o); }
     SDRBatch& operator^=(const SDRBatch& o) { return xori(o); }
     SDRBatch& operator-=(const SDRBatch& o) { return rmi(o); }
+    // SDR::shift (SDR.hpp:1579-1590) for every row: ids += amount, in place; << >> give a shifted copy, <<= >>= shift in
+    // place (SDR.hpp:461-468).  Refused (Error, SDRB_ERR_ID_RANGE) when an id would leave 32 bits or the declared width.
+    SDRBatch& shift(int amount, void* stream = nullptr) {
+        check(sdrb_batch_shift(h_, amount, stream));
+        return *this;
+    }
+    SDRBatch& operator<<=(int amount) { return shift(amount); }
+    SDRBatch& operator>>=(int amount) { return shift(-amount); }
+    SDRBatch operator<<(int amount) const { SDRBatch c = copy(); c.shift(amount); return c; }
+    SDRBatch operator>>(int amount) const { SDRBatch c = copy(); c.shift(-amount); return c; }
+    // a batch of its own with the same rows (device-to-device; batches of 32-bit ids)
+    SDRBatch copy(void* stream = nullptr) const {
+        if (id_bits_ != 32) throw Error(SDRB_ERR_UNSUPPORTED, "copy serves batches of 32-bit ids");
+        uint64_t nnz = 0;
+        int32_t width = 0;
+        check(sdrb_batch_info(h_, nullptr, nullptr, &nnz, &width, nullptr, nullptr));
+        detail::DeviceBuffer off(device_, (n_rows_ + 1) * sizeof(uint32_t)), ids(device_, (nnz ? nnz : 1) * sizeof(int32_t));
+        detail::DeviceBuffer data;
+        if (kind_ != SDRB_DATA_EMPTY) data = detail::DeviceBuffer(device_, (nnz ? nnz : 1) * sizeof(float));
+        check(sdrb_batch_export_device_csr(h_, static_cast<uint32_t*>(off.ptr), static_cast<int32_t*>(ids.ptr),
+                                           static_cast<float*>(data.ptr), stream));
+        SDRBatch c(device_, width, kind_);
+        check(sdrb_batch_upload_device_csr(c.h_, n_rows_, static_cast<const uint32_t*>(off.ptr), static_cast<const int32_t*>(ids.ptr),
+                                           static_cast<const float*>(data.ptr), stream));
+        check(sdrb_stream_sync(device_, stream));   // the buffers are released on return
+        c.n_rows_ = n_rows_;
+        return c;
+    }
 
     // Range queries: out(r, j) = (*this)[j].ands(lo[r], hi[r]), the ids of row j in [lo, hi) (SDR.hpp:931-956),
     // and the elements themselves, (*this)[j].ande(lo[r], hi[r]) (SDR.hpp:881-929), as a CSR over (r, j).

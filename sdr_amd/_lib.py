@@ -60,6 +60,7 @@ PROTOTYPES = {
     "sdrb_batch_adopt_device_csr": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_int32, C.c_int32]),
     "sdrb_batch_id_span": (C.c_int, [_vp, _i32p, _i32p]),
     "sdrb_batch_table_width": (C.c_int, [_vp, _i32p]),
+    "sdrb_batch_shift": (C.c_int, [_vp, C.c_int32, _vp]),
     "sdrb_batch_info": (C.c_int, [_vp, C.POINTER(C.c_int), _u64p, _u64p, _i32p, C.POINTER(C.c_int), _u32p]),
     "sdrb_batch_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "sdrb_batch_destroy": (C.c_int, [_vp]),

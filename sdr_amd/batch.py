@@ -690,6 +690,38 @@ class SDRBatch:
         self.upload_device(res.offsets, res.ids, res.data, stream=stream)
         return self
 
+    def shift(self, amount: int, *, stream=None) -> "SDRBatch":
+        """Adds ``amount`` to every id of every row, in place (``SDR::shift``, SDR.hpp:1579-1590).  Refused when an
+        id would leave 32 bits (the reference asserts the same) or the declared width."""
+        check(self._lib.sdrb_batch_shift(self._h, int(amount), _stream_handle(self.device, stream)))
+        self._generation += 1
+        return self
+
+    def copy(self, *, stream=None) -> "SDRBatch":
+        """A batch of its own with the same rows (device-to-device; batches of 32-bit ids)."""
+        if self.id_bits != 32:
+            raise ValueError("copy serves batches with 32-bit ids")
+        torch = _torch()
+        wire = self.to_wire(stream=stream)
+        n, nnz = self.n_rows, self.nnz
+        b = SDRBatch(self.device, self.width, self.data_kind)
+        data = wire[n + 1 + nnz:].view(torch.float32) if self.data_kind != DATA_EMPTY else None
+        b.upload_device(wire[: n + 1], wire[n + 1: n + 1 + nnz], data, stream=stream)
+        return b
+
+    # the reference's shift operators (SDR.hpp:461-468): << and >> give a shifted copy, <<= and >>= shift in place
+    def __lshift__(self, amount: int) -> "SDRBatch":
+        return self.copy().shift(amount)
+
+    def __rshift__(self, amount: int) -> "SDRBatch":
+        return self.copy().shift(-int(amount))
+
+    def __ilshift__(self, amount: int) -> "SDRBatch":
+        return self.shift(amount)
+
+    def __irshift__(self, amount: int) -> "SDRBatch":
+        return self.shift(-int(amount))
+
     def andi(self, other, *, stream=None) -> "SDRBatch":
         """Every row becomes ``row.andi(other[j])`` (SDR.hpp:1027-1081); the results equal ande's."""
         return self._inplace("ande", other, stream)

@@ -75,8 +75,12 @@ void drop_narrow(sdrb_batch* b) {
 }
 
 // Data derived from the rows (bit planes, dense byte matrix) dies with the content it was built from.
+void drop_tables(sdrb_batch* b);
 void drop_derived(sdrb_batch* b) {
     drop_narrow(b);
+    drop_tables(b);
+}
+void drop_tables(sdrb_batch* b) {
     if (b->d_bitplanes) (void)hipFree(b->d_bitplanes);
     if (b->d_dense8) (void)hipFree(b->d_dense8);
     b->d_bitplanes = nullptr;
@@ -549,6 +553,59 @@ int sdrb_batch_info(const sdrb_batch* batch, int* device, uint64_t* n_rows, uint
     if (width) *width = declared_width(batch);
     if (data_kind) *data_kind = batch->data_kind;
     if (max_row_len) *max_row_len = batch->max_row_len;
+    return SDRB_OK;
+}
+
+int sdrb_batch_shift(sdrb_batch* batch, int32_t amount, void* stream) {
+    TraceRange range("sdrb_batch_shift");
+    if (!batch) {
+        set_error("null batch handle");
+        return SDRB_ERR_INVALID_ARG;
+    }
+    if (!batch->owns_storage) {
+        set_error("sdrb_batch_shift: rows adopted from the caller's memory are not modified");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    if (batch->nnz == 0 || amount == 0) return SDRB_OK;
+    sdrb_batch* spans = batch->id_bits == 64 ? batch->narrow : batch;   // where the id span is known
+    if (!spans) {
+        set_error("sdrb_batch_shift: 64-bit ids beyond 32 bits are not shifted (their span is not kept)");
+        return SDRB_ERR_UNSUPPORTED;
+    }
+    const int64_t lo = (int64_t)spans->min_id + amount, hi = (int64_t)spans->max_id + amount;
+    const bool fits32 = lo >= INT32_MIN && hi <= INT32_MAX;
+    if (batch->id_bits == 32 && !fits32) {
+        // the reference asserts the same, SDR.hpp:1586
+        set_error("shift by %d takes ids out of 32 bits: they span [%d, %d]", amount, spans->min_id, spans->max_id);
+        return SDRB_ERR_ID_RANGE;
+    }
+    if (batch->width_declared && (lo < 0 || hi >= batch->width)) {
+        set_error("shift by %d takes ids out of the declared width %d: they span [%d, %d]", amount, batch->width,
+                  spans->min_id, spans->max_id);
+        return SDRB_ERR_ID_RANGE;
+    }
+    DeviceGuard guard(batch->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", batch->device);
+        return SDRB_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = launch_shift_ids(batch->d_ids, batch->id_bits, batch->nnz, amount, s);
+    if (rc != SDRB_OK) return rc;
+    drop_tables(batch);   // bit planes and byte matrix were those of the old ids
+    if (batch->id_bits == 64) {
+        if (!fits32) {
+            drop_narrow(batch);   // the shifted ids no longer fit 32 bits
+            return SDRB_OK;
+        }
+        rc = launch_shift_ids(batch->d_narrow_ids, 32, batch->nnz, amount, s);
+        if (rc != SDRB_OK) return rc;
+        drop_tables(spans);
+    }
+    spans->min_id = (int32_t)lo;
+    spans->max_id = (int32_t)hi;
+    if (batch->id_bits == 64) spans->width = lo >= 0 && hi < INT32_MAX ? (int32_t)hi + 1 : 0;
+    else settle_width(batch);
     return SDRB_OK;
 }
 

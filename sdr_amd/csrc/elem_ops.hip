@@ -440,6 +440,22 @@ int launch_narrow_ids(const int64_t* in, int32_t* out, uint64_t n, hipStream_t s
     return SDRB_OK;
 }
 
+template <typename Id>
+__global__ __launch_bounds__(256) void k_shift_ids(Id* __restrict__ ids, uint64_t n, Id amount) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) ids[k] += amount;
+}
+
+// ids[k] += amount (SDR::shift, SDR.hpp:1579-1590); the caller has checked that nothing overflows
+int launch_shift_ids(void* ids, int id_bits, uint64_t n, int64_t amount, hipStream_t stream) {
+    if (n == 0) return SDRB_OK;
+    const uint64_t blocks = (n + 255) / 256;
+    const dim3 grid((uint32_t)(blocks < 65536 ? blocks : 65536));
+    if (id_bits == 64) hipLaunchKernelGGL((k_shift_ids<long long>), grid, dim3(256), 0, stream, static_cast<long long*>(ids), n, (long long)amount);
+    else hipLaunchKernelGGL((k_shift_ids<int32_t>), grid, dim3(256), 0, stream, static_cast<int32_t*>(ids), n, (int32_t)amount);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
 int launch_widen_ids(const int32_t* in, int64_t* out, uint64_t n, hipStream_t stream) {
     if (n == 0) return SDRB_OK;
     const uint64_t blocks = (n + 255) / 256;

@@ -211,6 +211,7 @@ int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64
 // out[k] = in[k] widened to 64 bits (results of the 32-bit kernels for batches of 64-bit ids)
 int launch_widen_ids(const int32_t* in, int64_t* out, uint64_t n, hipStream_t stream);
 int launch_narrow_ids(const int64_t* in, int32_t* out, uint64_t n, hipStream_t stream);
+int launch_shift_ids(void* ids, int id_bits, uint64_t n, int64_t amount, hipStream_t stream);
 // In-place exclusive prefix sum of data[0..n) in one pass; entries at index >= n_valid count as zero (so a
 // scan over n = pairs + 1, n_valid = pairs leaves the total in data[pairs] without clearing it first).
 // Offsets are kept modulo 2^32; the exact 64-bit sum goes to *total_dev (device memory, may be null).

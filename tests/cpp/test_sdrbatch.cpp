@@ -529,6 +529,35 @@ int run_operators(std::mt19937& rng, const char* name) {
     c *= a;
     auto h = c.to_host();
     for (size_t j = 0; j < want.size(); ++j) REQUIRE(sdr_amd::Elements::unpack<R>(h, want.size(), 0, j) == want[j]);
+    // shift and its operators (SDR.hpp:461-468, 1579-1590; this file is built with the reference's asserts on, so its
+    // shift adds): in place, and as shifted copies that leave the batch alone; a batch without a declared width may
+    // go below zero, one with a width may not leave it
+    {
+        auto free_rows = sdr_amd::SDRBatch::pack(as.begin(), as.end(), 0, 0);
+        auto up = free_rows << 1000, down = free_rows >> 200;
+        free_rows <<= 7;
+        free_rows >>= 50;
+        auto h_up = up.to_host(), h_down = down.to_host(), h_in = free_rows.to_host();
+        for (size_t j = 0; j < as.size(); ++j) {
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_up, as.size(), 0, j) == (as[j] << 1000));
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_down, as.size(), 0, j) == (as[j] >> 200));
+            R moved(as[j]);
+            moved <<= 7;
+            moved >>= 50;
+            REQUIRE(sdr_amd::Elements::unpack<R>(h_in, as.size(), 0, j) == moved);
+        }
+        // the shifted rows still compute: overlaps with rows shifted the same way are those of the rows themselves
+        auto b_down = sdr_amd::SDRBatch::pack(bs.begin(), bs.end(), 0, 0) >> 200;
+        auto c_down = (down && b_down).to_host();
+        for (size_t i = 0; i < as.size(); ++i)
+            for (size_t j = 0; j < bs.size(); ++j) REQUIRE(c_down[i * bs.size() + j] == (as[i] && bs[j]));
+        bool refused = false;
+        try { a <<= 1000; } catch (const sdr_amd::Error& e) { refused = e.code() == SDRB_ERR_ID_RANGE; }
+        REQUIRE(refused);
+        refused = false;
+        try { up <<= 2147483000; } catch (const sdr_amd::Error& e) { refused = e.code() == SDRB_ERR_ID_RANGE; }
+        REQUIRE(refused);
+    }
     std::printf("ok %-28s %ld checks so far\n", name, g_checks);
     return 0;
 }

@@ -138,3 +138,46 @@ def test_transpose_of_large_batches_is_a_stable_regrouping(width, active, n, wit
     if with_data:
         t_data = wire[width + 1 + t.nnz:].view(np.float32)
         assert np.array_equal(t_data.view(np.uint32), data[order].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_shift_moves_every_id_and_keeps_the_rows_usable():
+    """``SDR::shift`` (SDR.hpp:1579-1590) and the operators built on it (SDR.hpp:461-468) for all rows at once: ids move
+    by the amount, payloads stay; a batch without a declared width may go below zero (and loses its derived width), one
+    with a width may not leave it; an overflow of 32 bits is refused, as the reference asserts."""
+    import sdr_amd
+    from sdr_amd import SDRBatch
+    rng = np.random.default_rng(8)
+    off, ids, data = util.ragged_rows(rng, 300, 2048, 40, True)
+    b = SDRBatch.from_csr(off, ids, data)
+    assert b.table_width() == int(ids.max()) + 1
+    q = SDRBatch.from_csr(off[:6], ids[: int(off[5])], data[: int(off[5])])
+    want = q.ands(b).cpu().numpy()
+    up = b << 5000                     # a copy
+    got = up.to_wire().cpu().numpy()
+    n, nnz = b.n_rows, b.nnz
+    assert np.array_equal(got[n + 1: n + 1 + nnz], ids + 5000) and np.array_equal(got[n + 1 + nnz:], data.view(np.int32))
+    assert up.table_width() == int(ids.max()) + 5001
+    assert np.array_equal(b.to_wire().cpu().numpy()[n + 1: n + 1 + nnz], ids)          # the original is untouched
+    assert np.array_equal((q << 5000).ands(up).cpu().numpy(), want)                    # table kernels on the derived width
+    down = b >> 3000                   # ids below zero: no width to derive, the label path
+    assert down.table_width() == 0
+    assert np.array_equal((q >> 3000).ands(down).cpu().numpy(), want)
+    b <<= 17
+    b >>= 17
+    assert np.array_equal(b.to_wire().cpu().numpy()[n + 1: n + 1 + nnz], ids)
+    assert np.array_equal(q.ands(b).cpu().numpy(), want)
+    declared = SDRBatch.from_csr(off, ids, data, width=2048)
+    with pytest.raises(sdr_amd.SdrbError) as e:
+        declared.shift(2048)
+    assert e.value.code == -3
+    with pytest.raises(sdr_amd.SdrbError) as e:
+        up.shift(2**31 - 6000)
+    assert e.value.code == -3
+    assert np.array_equal(q.ands(declared).cpu().numpy(), want)                        # a refused shift changes nothing
+    # 64-bit ids that fit 32 bits move with their narrowed twin
+    b64 = SDRBatch.from_csr(off, ids.astype(np.int64), data)
+    q64 = SDRBatch.from_csr(off[:6], ids[: int(off[5])].astype(np.int64), data[: int(off[5])])
+    b64.shift(-100)
+    q64.shift(-100)
+    assert np.array_equal(q64.ands(b64).cpu().numpy(), want)
