@@ -249,8 +249,35 @@ def one_query_regime(q1, shard, nd: int, dev) -> dict:
     ms = e0.elapsed_time(e1) / reps
     nbytes = algorithmic_bytes(1, nd)
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"workload": f"ands: 1 query x {nd} rows", "value": nd / (ms * 1e-3), "unit": "pair-ops/s",
-            "ms": ms, "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+    res = {"workload": f"ands: 1 query x {nd} rows", "value": nd / (ms * 1e-3), "unit": "pair-ops/s",
+           "ms": ms, "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+    # BASELINE.json configs[0], the reference's own CPU-runnable case, on the GPU: one query against 10 000 rows, as a
+    # caller sees it (launch included, counts left in HBM) and with the counts brought back to the host
+    import sdr_amd
+    from sdr_amd import SDRBatch
+    n_small = 10_000
+    small = SDRBatch.from_csr(*sdr_amd.synth_csr(1, 0, n_small, WIDTH, ACTIVE)[:2], None, width=WIDTH)
+    out_s = torch.empty((1, n_small), dtype=torch.int32, device=dev)
+    host = torch.empty((1, n_small), dtype=torch.int32).pin_memory()
+    for _ in range(3):
+        q1.ands(small, out=out_s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        q1.ands(small, out=out_s)
+    torch.cuda.synchronize()
+    call_us = (time.perf_counter() - t0) / 200 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(200):
+        q1.ands(small, out=out_s)
+        host.copy_(out_s, non_blocking=True)
+        torch.cuda.synchronize()
+    round_trip_us = (time.perf_counter() - t0) / 200 * 1e6
+    res["config1_1x10000"] = {"workload": f"ands: 1 query x {n_small} rows (the reference's CPU case)",
+                              "us_per_call_pipelined": call_us, "pair_ops_per_s_pipelined": n_small / (call_us * 1e-6),
+                              "us_per_call_with_counts_on_host": round_trip_us,
+                              "pair_ops_per_s_with_counts_on_host": n_small / (round_trip_us * 1e-6)}
+    return res
 
 
 def ingest_rates(dev) -> dict:
