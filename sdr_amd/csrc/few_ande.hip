@@ -237,9 +237,11 @@ __global__ __launch_bounds__(kBlock) void k_few_ande_count(
 
 // (2) group sums -> where every (row of A, group of B) starts in the result, in pair order (row of A major); the
 //     element total; the last offset.  One workgroup per row of A: it adds up the rows before its own (a few thousand
-//     values each) and scans its own.
+//     values each) and scans its own.  The starts go to an array of their own: the workgroups of later rows read the
+//     sums of earlier rows while those rows' workgroups are at work, in no order the launch promises.
 constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void k_few_ande_scan(uint32_t* __restrict__ group_total, uint32_t na,
+__global__ __launch_bounds__(kScanThreads) void k_few_ande_scan(const uint32_t* __restrict__ group_total,
+                                                               uint32_t* __restrict__ group_base, uint32_t na,
                                                                uint32_t n_groups,
                                                                unsigned long long* __restrict__ total_out,
                                                                uint32_t* __restrict__ last_offset) {
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(kScanThreads) void k_few_ande_scan(uint32_t* __rest
     before = 0;
     for (int w = 0; w < kScanThreads / 64; ++w) before += part64[w];
     // this row: every thread owns a run of consecutive groups
-    uint32_t* row = group_total + (uint64_t)q * n_groups;
+    const uint32_t* row = group_total + (uint64_t)q * n_groups;
+    uint32_t* row_base = group_base + (uint64_t)q * n_groups;
     const uint32_t per = (n_groups + kScanThreads - 1) / kScanThreads;
     const uint32_t g0 = tid * per < n_groups ? tid * per : n_groups, g1 = g0 + per < n_groups ? g0 + per : n_groups;
     uint32_t mine = 0;
@@ -282,9 +285,8 @@ __global__ __launch_bounds__(kScanThreads) void k_few_ande_scan(uint32_t* __rest
         row_sum += part32[w];
     }
     for (uint32_t g = g0; g < g1; ++g) {
-        const uint32_t v = row[g];
-        row[g] = run;
-        run += v;
+        row_base[g] = run;
+        run += row[g];
     }
     if (q + 1 == na && tid == 0) {
         *total_out = before + row_sum;
@@ -528,6 +530,7 @@ int launch_all(const sdrb_batch* a, const sdrb_batch* b, const FewPlan& p, const
                uint32_t* group_total, uint32_t* out_offsets, int32_t* out_ids, float* out_data, uint64_t capacity,
                unsigned long long* total_dev, hipStream_t stream) {
     const uint32_t na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
+    uint32_t* group_base = group_total + (size_t)na * p.n_groups;
     if (p.lds > 64 * 1024) {   // dynamic LDS beyond 64 KiB has to be granted per kernel
         SDRB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_few_ande_count<MATH, NCH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -537,11 +540,11 @@ int launch_all(const sdrb_batch* a, const sdrb_batch* b, const FewPlan& p, const
     hipLaunchKernelGGL((k_few_ande_count<MATH, NCH>), dim3(p.grid), dim3(kBlock), p.lds, stream, b->d_offsets, b->d_ids,
                        b->d_data, nb, tables, p.tile_bytes, (uint32_t)p.wcap, na, cnt8, group_total, p.n_groups);
     SDRB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, na, p.n_groups, total_dev,
-                       out_offsets + (uint64_t)na * nb);
+    hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, group_base, na, p.n_groups,
+                       total_dev, out_offsets + (uint64_t)na * nb);
     SDRB_HIP(hipGetLastError());
     hipLaunchKernelGGL((k_few_ande_fill<MATH, NCH>), dim3(p.grid), dim3(kBlock), p.lds, stream, b->d_offsets, b->d_ids,
-                       b->d_data, nb, tables, p.tile_bytes, (uint32_t)p.wcap, na, cnt8, group_total, p.n_groups, out_offsets,
+                       b->d_data, nb, tables, p.tile_bytes, (uint32_t)p.wcap, na, cnt8, group_base, p.n_groups, out_offsets,
                        out_ids, out_data, capacity);
     SDRB_HIP(hipGetLastError());
     return SDRB_OK;
@@ -576,11 +579,12 @@ int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_
         const uint32_t na = (uint32_t)a->n_rows, nb = (uint32_t)b->n_rows;
         const size_t pairs = (size_t)na * nb;
         const size_t mask_bytes_all = pairs * sizeof(unsigned long long), cnt_bytes = (pairs + 255) & ~(size_t)255;
-        char* ws = static_cast<char*>(workspace(b->device, stream, 12, mask_bytes_all + cnt_bytes + (size_t)na * p.n_groups * sizeof(uint32_t)));
+        char* ws = static_cast<char*>(workspace(b->device, stream, 12, mask_bytes_all + cnt_bytes + 2 * (size_t)na * p.n_groups * sizeof(uint32_t)));
         if (!ws) return SDRB_ERR_HIP;
         unsigned long long* pos_mask = reinterpret_cast<unsigned long long*>(ws);
         uint8_t* cnt8 = reinterpret_cast<uint8_t*>(ws + mask_bytes_all);
         uint32_t* group_total = reinterpret_cast<uint32_t*>(ws + mask_bytes_all + cnt_bytes);
+        uint32_t* group_base = group_total + (size_t)na * p.n_groups;
         const bool self_a = p.math == kSelfA;
 #define SDRB_MASKS_COUNT_R(NCH, SELF, ROWS)                                                                             \
     do {                                                                                                                 \
@@ -607,15 +611,15 @@ int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_
 #undef SDRB_MASKS_COUNT
 #undef SDRB_MASKS_COUNT_R
         SDRB_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, na, p.n_groups, total_dev,
-                           out_offsets + (uint64_t)na * nb);
+        hipLaunchKernelGGL(k_few_ande_scan, dim3(na), dim3(kScanThreads), 0, stream, group_total, group_base, na, p.n_groups,
+                           total_dev, out_offsets + (uint64_t)na * nb);
         SDRB_HIP(hipGetLastError());
         if (self_a)
             hipLaunchKernelGGL((k_few_masks_fill<true>), dim3(p.grid), dim3(kBlock), 0, stream, a->d_offsets, a->d_ids, a->d_data, na,
-                               nb, pos_mask, cnt8, group_total, p.n_groups, out_offsets, out_ids, out_data, capacity);
+                               nb, pos_mask, cnt8, group_base, p.n_groups, out_offsets, out_ids, out_data, capacity);
         else
             hipLaunchKernelGGL((k_few_masks_fill<false>), dim3(p.grid), dim3(kBlock), 0, stream, a->d_offsets, a->d_ids, a->d_data, na,
-                               nb, pos_mask, cnt8, group_total, p.n_groups, out_offsets, out_ids, out_data, capacity);
+                               nb, pos_mask, cnt8, group_base, p.n_groups, out_offsets, out_ids, out_data, capacity);
         SDRB_HIP(hipGetLastError());
         return SDRB_OK;
     }
@@ -625,7 +629,7 @@ int launch_few_ande(const sdrb_batch* a, const sdrb_batch* b, bool swap, uint32_
     int rc = build_lane_tiles(a, b->device, p.wcap, with_vals, stream, &tile_bytes, &ntiles, &tables);
     if (rc != SDRB_OK) return rc;
     const size_t cnt_bytes = ((size_t)a->n_rows * b->n_rows + 255) & ~(size_t)255;
-    char* ws = static_cast<char*>(workspace(b->device, stream, 12, cnt_bytes + (size_t)a->n_rows * p.n_groups * sizeof(uint32_t)));
+    char* ws = static_cast<char*>(workspace(b->device, stream, 12, cnt_bytes + 2 * (size_t)a->n_rows * p.n_groups * sizeof(uint32_t)));
     if (!ws) return SDRB_ERR_HIP;
     uint8_t* cnt8 = reinterpret_cast<uint8_t*>(ws);
     uint32_t* group_total = reinterpret_cast<uint32_t*>(ws + cnt_bytes);

@@ -799,6 +799,25 @@ def test_fused_few_rows_ande_refills_when_the_estimate_is_too_small():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nq,width,len_t,len_a,na", [(32, 64, 8, 4, 64), (17, 8, 8, 1, 64), (8, 2048, 40, 40, 5000)])
+def test_fused_few_rows_ande_is_the_same_every_time(nq, width, len_t, len_a, na):
+    """The scan between count and fill runs one workgroup a row of `this`, each adding up the sums of the rows before
+    its own: those sums must still be there whenever a workgroup gets to run (a scan that wrote its starts over them
+    was right almost always, and wrong when a workgroup started late).  Many rows, tiny work, many repeats."""
+    import torch
+    rng = np.random.default_rng(nq * 1000 + na)
+    t = Batch(*util.ragged_rows(rng, nq, width, len_t, False))
+    a = Batch(*util.ragged_rows(rng, na, width, len_a, True))
+    dt, da = dev(t, width), dev(a, width)
+    first = dt.ande(da)
+    assert first._total_dev is not None
+    assert_elems_equal(first.to_host(), oracle.port().elem_op(AND, t, a))
+    for _ in range(400):
+        again = dt.ande(da)
+        assert torch.equal(again.offsets, first.offsets) and torch.equal(again.ids[: first.total], first.ids[: first.total])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["UU", "UE"])
 @pytest.mark.parametrize("len_t,fused", [(310, True), (450, False)])
 def test_few_rows_ande_with_more_payloads_than_16_bit_offsets_reach(name, len_t, fused):

@@ -2,7 +2,7 @@
 """Randomised soak run on the GPU: random shapes, payload kinds, ops and orientations through the default kernel
 choice -- sizes, elements, and in turn the visitors' records, operator==, 64-bit ids, dot products, the row-wise forms,
 range and point queries, narrow counts, ids without a usable width -- every
-result compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big|algos|long]
+result compared with the CPU oracle bit for bit.  usage: soak.py [seconds] [seed] [big|algos|long|-] [first case]
 Prints a line per 50 cases and a summary; exits non-zero on the first mismatch (the failing case is printed so that
 it can be replayed from its seed)."""
 import os
@@ -30,7 +30,7 @@ def main():
     algos = len(sys.argv) > 3 and sys.argv[3] in ("algos", "long")
     long_rows = len(sys.argv) > 3 and sys.argv[3] == "long"
     t_end = time.time() + budget
-    case = 0
+    case = int(sys.argv[4]) if len(sys.argv) > 4 else 0     # replay: the case a failing seed names (seed - seed0 * 1000003)
     checks = 0
     while time.time() < t_end:
         seed = seed0 * 1000003 + case
