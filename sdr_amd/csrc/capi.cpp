@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -351,7 +352,16 @@ void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fr
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (!g_retired.empty()) reap_retired(device);
     Scratch& s = g_ws[ScratchKey{device, stream, slot}];
-    if (s.bytes >= bytes && s.ptr) return s.ptr;
+    // SDRB_POISON_WORKSPACE=1 (test runs): every block handed out is filled with 0xA5 first, so that a kernel which
+    // counts on what an earlier call, or a fresh allocation, happened to leave there shows up as a wrong result
+    static const bool poison = [] {
+        const char* e = std::getenv("SDRB_POISON_WORKSPACE");
+        return e && *e && *e != '0';
+    }();
+    if (s.bytes >= bytes && s.ptr) {
+        if (poison) (void)hipMemsetAsync(s.ptr, 0xA5, s.bytes, stream);
+        return s.ptr;
+    }
     const size_t old_bytes = s.bytes;
     if (s.ptr) {
         // kernels already enqueued on this stream may still read the old block: it is freed after them
@@ -377,6 +387,7 @@ void* workspace(int device, hipStream_t stream, int slot, size_t bytes, bool* fr
     }
     s.bytes = want;
     if (fresh) *fresh = true;
+    if (poison) (void)hipMemsetAsync(s.ptr, 0xA5, s.bytes, stream);
     return s.ptr;
 }
 
