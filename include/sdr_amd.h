@@ -156,6 +156,12 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
  * fit 32 bits, which such a result could not hold).  Ids compare by value; the reference, handed a `long` id beyond
  * 32 bits in a search over `int` elements, truncates it (SDRElem.hpp:73-75 takes the element's own id type), so
  * that case has no reference result to match.  Everything else refuses 64-bit batches.
+ *
+ * Ids no table indexes as they are -- some negative, 64-bit ids far from zero -- but within 32 768 of each other over
+ * BOTH batches of a call are moved for the call: the kernels see copies of the ids less the smallest one (a pass over
+ * each batch, scratch of the stream), with every table kernel open to them, and an element fill adds it back.  Results
+ * depend on which ids are equal and on their order, never on their values (SDRElem.hpp:56-75).  Ids further apart are
+ * given small labels for the size ops (batches without a usable width above) and merged pair by pair for the elements.
  */
 int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out);
 int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,
@@ -184,8 +190,9 @@ int sdrb_batch_id_span(const sdrb_batch* batch, int32_t* min_id, int32_t* max_id
  * Adds `amount` to every id of the batch, in place, on `stream`: SDR::shift (SDR.hpp:1579-1590) and the operators
  * << >> <<= >>= built on it (SDR.hpp:461-468), for all rows at once.  The reference asserts that no id overflows
  * (SDR.hpp:1586); here such a shift is refused with SDRB_ERR_ID_RANGE and nothing is changed, and so is one that
- * takes an id out of a declared width.  Batches of 64-bit ids are shifted while their ids fit 32 bits beforehand
- * (the id span of others is not kept); rows adopted from caller memory are not modified (SDRB_ERR_UNSUPPORTED).
+ * takes an id out of a declared width.  Batches of 64-bit ids are shifted within 64 bits (ids that leave 32 bits lose
+ * their narrowed copy; ids that come to fit 32 bits get none before the next upload); rows adopted from caller memory
+ * are not modified (SDRB_ERR_UNSUPPORTED).
  */
 int sdrb_batch_shift(sdrb_batch* batch, int32_t amount, void* stream);
 

@@ -692,7 +692,7 @@ class SDRBatch:
 
     def shift(self, amount: int, *, stream=None) -> "SDRBatch":
         """Adds ``amount`` to every id of every row, in place (``SDR::shift``, SDR.hpp:1579-1590).  Refused when an
-        id would leave 32 bits (the reference asserts the same) or the declared width."""
+        id would leave 32 bits (the reference asserts the same) or the declared width; 64-bit ids stay within 64 bits."""
         check(self._lib.sdrb_batch_shift(self._h, int(amount), _stream_handle(self.device, stream)))
         self._generation += 1
         return self

@@ -108,6 +108,8 @@ void free_batch_storage(sdrb_batch* b) {
     b->max_row_len = 0;
     b->min_id = 0;
     b->max_id = -1;
+    b->min_id64 = 0;
+    b->max_id64 = -1;
     settle_width(b);
 }
 
@@ -228,12 +230,113 @@ bool narrow_pair(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags) {
 // taken through its 32-bit twin when it keeps one (every kernel of the 32-bit path then applies); when its ids do not
 // fit 32 bits, the 32-bit batch is taken through a widened copy of its ids (scratch of the call's stream) and the pair
 // runs on the 64-bit kernels.  Batches of equal width: narrow_pair.  After the call both pointers name batches of one
-// width; `h` keeps the widened view alive for the call.
+// width; `h` keeps the views alive for the call.
+//
+// Ids that no table can index as they are but that lie close together -- some of them negative, or 64-bit ids far from
+// zero -- are moved first: what a set operation yields depends on which ids are equal and on their order, never on their
+// values, so both batches are seen through copies of their ids less the smallest id of the two (32-bit ids in [0, span),
+// scratch of the call's stream), with the span as their width; every kernel of the 32-bit path then applies, and an
+// element fill adds the smallest id back to its result (IdHarmony::moved, ::base).  Spans beyond kMovedSpan stay on the
+// labels (relabel.hip) and the merges.
+constexpr unsigned kFlagIdsAsTheyAre = 1u << 29;   // internal: a caller whose kernels are merges anyway (operator==)
+constexpr int64_t kMovedSpan = 32768;   // the widest table of the element kernels (elem_rank.hip)
 struct IdHarmony {
     sdrb_batch wide;
+    sdrb_batch at_zero[2];   // a and b with their ids moved
+    bool moved = false;
+    int64_t base = 0;        // what was subtracted
+    hipStream_t stream = nullptr;
+    IdHarmony() = default;
+    IdHarmony(const IdHarmony&) = delete;
+    IdHarmony& operator=(const IdHarmony&) = delete;
+    ~IdHarmony() {
+        if (!moved) return;
+        // a form derived inside the call (bit planes of the moved ids) belongs to the views, which end here
+        bool any = false;
+        for (sdrb_batch& v : at_zero) any = any || v.d_bitplanes || v.d_dense8;
+        if (!any) return;
+        (void)hipStreamSynchronize(stream);
+        for (sdrb_batch& v : at_zero) drop_tables(&v);
+    }
 };
+
+// the ids' span where it is known: false for an empty batch or a 64-bit batch nobody has looked through
+bool id_span(const sdrb_batch* b, int64_t* lo, int64_t* hi) {
+    if (b->nnz == 0) return false;
+    if (b->id_bits == 32) {
+        *lo = b->min_id;
+        *hi = b->max_id;
+    } else {
+        *lo = b->min_id64;
+        *hi = b->max_id64;
+    }
+    return *lo <= *hi;
+}
+
+int move_ids_to_zero(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags, hipStream_t s, IdHarmony* h) {
+    // (row by row, and where the caller asks for them, the merges serve: they take ids as they are)
+    if ((flags & (SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE | kFlagLabelled | kFlagIdsAsTheyAre)) || a->device != b->device ||
+        !a->d_offsets || !b->d_offsets)
+        return SDRB_OK;
+    const sdrb_batch* e[2] = {a->id_bits == 64 && a->narrow ? a->narrow : a, b->id_bits == 64 && b->narrow ? b->narrow : b};
+    // Served by the tables as they are: those are indexed by the ids of b, and ids of a outside b's width match nothing
+    // there (a width beyond every table, declared or derived, serves nobody).
+    const bool b_served = e[1]->id_bits == 32 && ((e[1]->width > 0 && e[1]->width <= kMovedSpan) || e[1]->nnz == 0);
+    if (b_served && e[0]->id_bits == 32) return SDRB_OK;
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (const sdrb_batch* x : e) {
+        if (x->nnz == 0) continue;
+        int64_t xlo, xhi;
+        if (!id_span(x, &xlo, &xhi)) return SDRB_OK;
+        lo = std::min(lo, xlo);
+        hi = std::max(hi, xhi);
+    }
+    if (lo > hi || (uint64_t)hi - (uint64_t)lo >= (uint64_t)kMovedSpan) return SDRB_OK;
+    DeviceGuard guard(a->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", a->device);
+        return SDRB_ERR_HIP;
+    }
+    for (int k = 0; k < 2; ++k) {
+        sdrb_batch& v = h->at_zero[k];
+        v = *e[k];
+        v.id_bits = 32;
+        v.width = (int32_t)(hi - lo + 1);
+        v.width_declared = true;
+        v.owns_storage = false;
+        v.narrow = nullptr;
+        v.d_narrow_ids = nullptr;
+        v.derived_home = nullptr;
+        v.d_bitplanes = nullptr;
+        v.d_dense8 = nullptr;
+        v.bitplanes_ready = v.dense_ready = nullptr;
+        v.min_id = 0;
+        v.max_id = -1;
+        int64_t xlo, xhi;
+        if (id_span(e[k], &xlo, &xhi)) {
+            v.min_id = (int32_t)(xlo - lo);
+            v.max_id = (int32_t)(xhi - lo);
+        }
+        if (v.nnz) {
+            int32_t* ids = static_cast<int32_t*>(workspace(v.device, s, 15 + k, (size_t)v.nnz * sizeof(int32_t)));
+            if (!ids) return SDRB_ERR_HIP;
+            const int rc = launch_rebase_ids(e[k]->d_ids, e[k]->id_bits, ids, v.nnz, lo, s);
+            if (rc != SDRB_OK) return rc;
+            v.d_ids = ids;
+        }
+    }
+    h->moved = true;
+    h->base = lo;
+    h->stream = s;
+    a = &h->at_zero[0];
+    b = &h->at_zero[1];
+    return SDRB_OK;
+}
+
 int harmonise_ids(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags, hipStream_t s, IdHarmony* h) {
     if (!a || !b) return SDRB_OK;   // the checks that follow name the null handle
+    const int mrc = move_ids_to_zero(a, b, flags, s, h);
+    if (mrc != SDRB_OK || h->moved) return mrc;
     if (a->id_bits == b->id_bits) {
         narrow_pair(a, b, flags);
         return SDRB_OK;
@@ -257,6 +360,8 @@ int harmonise_ids(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags, hi
     v.d_bitplanes = nullptr;
     v.d_dense8 = nullptr;
     v.bitplanes_ready = v.dense_ready = nullptr;
+    v.min_id64 = slim->min_id;
+    v.max_id64 = slim->max_id;
     if (slim->nnz) {
         DeviceGuard guard(slim->device);
         if (!guard.ok) {
@@ -336,6 +441,8 @@ void clear_batch_rows(sdrb_batch* b) {
     b->max_row_len = 0;
     b->min_id = 0;
     b->max_id = -1;
+    b->min_id64 = 0;
+    b->max_id64 = -1;
 }
 
 void set_error(const char* fmt, ...) {
@@ -580,8 +687,22 @@ int sdrb_batch_shift(sdrb_batch* batch, int32_t amount, void* stream) {
     if (batch->nnz == 0 || amount == 0) return SDRB_OK;
     sdrb_batch* spans = batch->id_bits == 64 ? batch->narrow : batch;   // where the id span is known
     if (!spans) {
-        set_error("sdrb_batch_shift: 64-bit ids beyond 32 bits are not shifted (their span is not kept)");
-        return SDRB_ERR_UNSUPPORTED;
+        // 64-bit ids beyond 32 bits: their span, where the upload has left it, says whether the shift stays inside 64 bits
+        if (batch->min_id64 > batch->max_id64 || (amount > 0 ? batch->max_id64 > INT64_MAX - amount : batch->min_id64 < INT64_MIN - amount)) {
+            set_error("sdrb_batch_shift: these 64-bit ids cannot be shifted by %d (span unknown, or the shift leaves 64 bits)", amount);
+            return SDRB_ERR_ID_RANGE;
+        }
+        DeviceGuard wide_guard(batch->device);
+        if (!wide_guard.ok) {
+            set_error("hipSetDevice(%d) failed", batch->device);
+            return SDRB_ERR_HIP;
+        }
+        const int wrc = launch_shift_ids(batch->d_ids, 64, batch->nnz, amount, static_cast<hipStream_t>(stream));
+        if (wrc != SDRB_OK) return wrc;
+        drop_tables(batch);
+        batch->min_id64 += amount;
+        batch->max_id64 += amount;
+        return SDRB_OK;   // (no 32-bit twin is made even where the shifted ids would now fit one)
     }
     const int64_t lo = (int64_t)spans->min_id + amount, hi = (int64_t)spans->max_id + amount;
     const bool fits32 = lo >= INT32_MIN && hi <= INT32_MAX;
@@ -605,6 +726,8 @@ int sdrb_batch_shift(sdrb_batch* batch, int32_t amount, void* stream) {
     if (rc != SDRB_OK) return rc;
     drop_tables(batch);   // bit planes and byte matrix were those of the old ids
     if (batch->id_bits == 64) {
+        batch->min_id64 = lo;
+        batch->max_id64 = hi;
         if (!fits32) {
             drop_narrow(batch);   // the shifted ids no longer fit 32 bits
             return SDRB_OK;
@@ -615,6 +738,10 @@ int sdrb_batch_shift(sdrb_batch* batch, int32_t amount, void* stream) {
     }
     spans->min_id = (int32_t)lo;
     spans->max_id = (int32_t)hi;
+    if (batch->id_bits == 64) {
+        batch->min_id64 = lo;
+        batch->max_id64 = hi;
+    }
     if (batch->id_bits == 64) spans->width = lo >= 0 && hi < INT32_MAX ? (int32_t)hi + 1 : 0;
     else settle_width(batch);
     return SDRB_OK;
@@ -879,7 +1006,7 @@ int sdrb_size_op_static(const sdrb_batch* a, const sdrb_batch* b, int op, unsign
 int sdrb_equal(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, uint32_t* out, uint64_t ld_out, void* stream) {
     TraceRange range("sdrb_equal");
     IdHarmony harmony;
-    int rc = harmonise_ids(a, b, flags, static_cast<hipStream_t>(stream), &harmony);
+    int rc = harmonise_ids(a, b, flags | kFlagIdsAsTheyAre, static_cast<hipStream_t>(stream), &harmony);
     if (rc == SDRB_OK) rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_set_algebra_kinds(a, b, SDRB_OP_AND);
     if (rc != SDRB_OK) return rc;
@@ -1217,16 +1344,44 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
             return SDRB_ERR_INVALID_ARG;
         }
         hipStream_t s = static_cast<hipStream_t>(stream);
+        const sdrb_batch* arg0 = (flags & SDRB_FLAG_SWAP) ? a : b;
+        if (want_bits == 32 && arg0->id_bits == 64 && !arg0->narrow && (op == SDRB_OP_OR || op == SDRB_OP_XOR)) {
+            set_error("a union of 32-bit `this` rows with 64-bit ids that do not fit 32 bits has no 32-bit result");
+            return SDRB_ERR_UNSUPPORTED;
+        }
         const sdrb_batch *na = a, *nb = b;
         const int hrc = harmonise_ids(na, nb, flags, s, &harmony);
         if (hrc != SDRB_OK) return hrc;
-        if (na->id_bits == nb->id_bits && na->id_bits != want_bits) {
-            if (want_bits == 32 && (op == SDRB_OP_OR || op == SDRB_OP_XOR)) {
-                set_error("a union of 32-bit `this` rows with 64-bit ids that do not fit 32 bits has no 32-bit result");
-                return SDRB_ERR_UNSUPPORTED;
+        const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
+        const uint64_t pairs = rowwise ? nb->n_rows : na->n_rows * nb->n_rows;
+        if (harmony.moved) {
+            // the pair ran on ids less harmony.base: the fill's ids get it back (and `this`'s width on the way)
+            if (rowwise && na->n_rows != nb->n_rows) {
+                set_error("row-wise evaluation needs batches of equal length");
+                return SDRB_ERR_INVALID_ARG;
             }
-            const bool rowwise = (flags & SDRB_FLAG_ROWWISE) != 0;
-            const uint64_t pairs = rowwise ? nb->n_rows : na->n_rows * nb->n_rows;
+            if (pairs == 0) return SDRB_OK;
+            DeviceGuard guard(nb->device);
+            if (!guard.ok) {
+                set_error("hipSetDevice(%d) failed", nb->device);
+                return SDRB_ERR_HIP;
+            }
+            if (want_bits == 32) {
+                const int rc_inner = elem_op_fill_any(na, nb, op, flags, out_offsets, out_ids_any, 32, out_data, stream);
+                if (rc_inner != SDRB_OK) return rc_inner;
+                return launch_unbase_ids32(static_cast<int32_t*>(out_ids_any), out_offsets + pairs, (int32_t)harmony.base, s);
+            }
+            uint32_t total = 0;
+            SDRB_HIP(hipMemcpyAsync(&total, out_offsets + pairs, sizeof total, hipMemcpyDeviceToHost, s));
+            SDRB_HIP(hipStreamSynchronize(s));
+            if (total == 0) return SDRB_OK;
+            int32_t* tmp = static_cast<int32_t*>(workspace(nb->device, s, 11, (size_t)total * sizeof(int32_t)));
+            if (!tmp) return SDRB_ERR_HIP;
+            const int rc_inner = elem_op_fill_any(na, nb, op, flags, out_offsets, tmp, 32, out_data, stream);
+            if (rc_inner != SDRB_OK) return rc_inner;
+            return launch_unbase_ids64(tmp, static_cast<int64_t*>(out_ids_any), out_offsets + pairs, harmony.base, s);
+        }
+        if (na->id_bits == nb->id_bits && na->id_bits != want_bits) {
             DeviceGuard guard(nb->device);
             if (!guard.ok) {
                 set_error("hipSetDevice(%d) failed", nb->device);

@@ -456,6 +456,43 @@ int launch_shift_ids(void* ids, int id_bits, uint64_t n, int64_t amount, hipStre
     return SDRB_OK;
 }
 
+template <typename Id>
+__global__ __launch_bounds__(256) void k_rebase_ids(const Id* __restrict__ in, int32_t* __restrict__ out, uint64_t n, Id base) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) out[k] = (int32_t)(in[k] - base);
+}
+
+int launch_rebase_ids(const void* in, int id_bits, int32_t* out, uint64_t n, int64_t base, hipStream_t stream) {
+    if (n == 0) return SDRB_OK;
+    const uint64_t blocks = (n + 255) / 256;
+    const dim3 grid((uint32_t)(blocks < 65536 ? blocks : 65536));
+    if (id_bits == 64) hipLaunchKernelGGL((k_rebase_ids<long long>), grid, dim3(256), 0, stream, static_cast<const long long*>(in), out, n, (long long)base);
+    else hipLaunchKernelGGL((k_rebase_ids<int32_t>), grid, dim3(256), 0, stream, static_cast<const int32_t*>(in), out, n, (int32_t)base);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
+// the element count of a result lives on the device (its last offset): the grid is fixed and strides over it
+__global__ __launch_bounds__(256) void k_unbase_ids32(int32_t* __restrict__ ids, const uint32_t* __restrict__ n_dev, int32_t base) {
+    const uint64_t n = *n_dev;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) ids[k] += base;
+}
+__global__ __launch_bounds__(256) void k_unbase_ids64(const int32_t* __restrict__ in, int64_t* __restrict__ out,
+                                                      const uint32_t* __restrict__ n_dev, long long base) {
+    const uint64_t n = *n_dev;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) out[k] = (long long)in[k] + base;
+}
+
+int launch_unbase_ids32(int32_t* ids, const uint32_t* n_dev, int32_t base, hipStream_t stream) {
+    hipLaunchKernelGGL(k_unbase_ids32, dim3(2048), dim3(256), 0, stream, ids, n_dev, base);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+int launch_unbase_ids64(const int32_t* in, int64_t* out, const uint32_t* n_dev, int64_t base, hipStream_t stream) {
+    hipLaunchKernelGGL(k_unbase_ids64, dim3(2048), dim3(256), 0, stream, in, out, n_dev, (long long)base);
+    SDRB_HIP(hipGetLastError());
+    return SDRB_OK;
+}
+
 int launch_widen_ids(const int32_t* in, int64_t* out, uint64_t n, hipStream_t stream) {
     if (n == 0) return SDRB_OK;
     const uint64_t blocks = (n + 255) / 256;

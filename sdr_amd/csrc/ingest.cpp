@@ -986,6 +986,8 @@ static int upload_csr64_impl(sdrb_batch* batch, uint64_t n_rows, const uint64_t*
     batch->max_id = -1;
     // ids that all fit 32 bits (the reference's SDRElem<long> rows usually do): keep them narrowed as well
     const bool any = f.min_id <= f.max_id;
+    batch->min_id64 = any ? (int64_t)f.min_id : 0;
+    batch->max_id64 = any ? (int64_t)f.max_id : -1;
     if (!any || (f.min_id >= INT32_MIN && f.max_id < INT32_MAX)) {
         DeviceGuard guard(batch->device);
         if (nnz) {

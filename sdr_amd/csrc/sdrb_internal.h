@@ -26,6 +26,7 @@ struct sdrb_batch {
     uint64_t nnz = 0;
     uint32_t max_row_len = 0;
     int32_t min_id = 0, max_id = -1;  // over all rows (max_id < min_id when empty)
+    int64_t min_id64 = 0, max_id64 = -1;   // a batch of 64-bit ids: their span, where an upload has looked at them (else max < min)
     uint32_t* d_offsets = nullptr;    // [n_rows + 1]
     int32_t* d_ids = nullptr;         // [nnz]
     float* d_data = nullptr;          // [nnz] or null
@@ -212,6 +213,11 @@ int launch_equal(const sdrb_batch* a, const sdrb_batch* b, uint32_t* out, uint64
 int launch_widen_ids(const int32_t* in, int64_t* out, uint64_t n, hipStream_t stream);
 int launch_narrow_ids(const int64_t* in, int32_t* out, uint64_t n, hipStream_t stream);
 int launch_shift_ids(void* ids, int id_bits, uint64_t n, int64_t amount, hipStream_t stream);
+// out[k] = (int32)(in[k] - base): ids moved to start at zero (in: 32- or 64-bit ids whose distance from base fits 31 bits)
+int launch_rebase_ids(const void* in, int id_bits, int32_t* out, uint64_t n, int64_t base, hipStream_t stream);
+// ids[k] += base for k < *n_dev (n_dev: device memory -- the last offset of a result); 64-bit: from the 32-bit ids in `in`
+int launch_unbase_ids32(int32_t* ids, const uint32_t* n_dev, int32_t base, hipStream_t stream);
+int launch_unbase_ids64(const int32_t* in, int64_t* out, const uint32_t* n_dev, int64_t base, hipStream_t stream);
 // In-place exclusive prefix sum of data[0..n) in one pass; entries at index >= n_valid count as zero (so a
 // scan over n = pairs + 1, n_valid = pairs leaves the total in data[pairs] without clearing it first).
 // Offsets are kept modulo 2^32; the exact 64-bit sum goes to *total_dev (device memory, may be null).

@@ -53,11 +53,15 @@ def test_default_choice_for_long_id_only_rows_and_payload_batches():
     with pytest.raises(_lib.SdrbError) as e:
         sizes(AND, dt, da, algo="bitslice_long")
     assert e.value.code == -5
-    # widths beyond the LDS are refused
-    wide = SDRBatch.from_csr(a.off, a.ids, None, width=100_000)
+    # widths beyond the LDS are refused when the ids spread over them
+    wide = SDRBatch.from_csr(a.off, a.ids * 6, None, width=100_000)
     with pytest.raises(_lib.SdrbError) as e:
-        sizes(OR, SDRBatch.from_csr(t.off, t.ids, None, width=100_000), wide, algo="bitslice_long")
+        sizes(OR, SDRBatch.from_csr(t.off, t.ids * 6, None, width=100_000), wide, algo="bitslice_long")
     assert e.value.code == -5
+    # ... and served when the ids all lie in a window a table holds (they are moved to zero for the call)
+    window = SDRBatch.from_csr(a.off, a.ids + 70_000, None, width=100_000)
+    got = sizes(OR, SDRBatch.from_csr(t.off, t.ids + 70_000, None, width=100_000), window, algo="bitslice_long")
+    assert np.array_equal(got, want)
 
 
 def test_full_share_of_config_4_id_only():

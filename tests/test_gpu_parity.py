@@ -328,8 +328,8 @@ def test_rank_table_kernel_refuses_what_it_cannot_hold():
     a = Batch(*util.ragged_rows(rng, 9, 200, 20, False))
     with pytest.raises(sdr_amd.SdrbError):          # ids of `this` beyond the declared width of the other side
         gpu_elems(OR, dev(t, 300), dev(a, 200), algo="rank")
-    neg = Batch(a.off, a.ids - 7, a.data)
-    with pytest.raises(sdr_amd.SdrbError):          # no declared width and none to derive: a negative id
+    neg = Batch(a.off, (a.ids - 7) * 1000003, a.data)
+    with pytest.raises(sdr_amd.SdrbError):          # no declared width and none to derive: a negative id, ids far apart
         gpu_elems(OR, dev(neg), dev(neg), algo="rank")
     # no declared width, no negative id: served as if the largest id + 1 had been declared
     assert_elems_equal(gpu_elems(OR, dev(a), dev(a), algo="rank"), oracle.port().elem_op(OR, a, a))

@@ -26,9 +26,12 @@ def spread(ids, factor, shift):
 
 
 @pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("apart", [70001, 1])
 @pytest.mark.parametrize("nt,na,len_t,len_a", [(1, 3000, 40, 40), (70, 1500, 40, 40), (300, 700, 40, 40), (5, 600, 300, 500),
                                                (130, 400, 64, 64), (9, 300, 2000, 33), (3, 257, 0, 40)])
-def test_widthless_sizes_vs_oracle_and_merge(name, nt, na, len_t, len_a):
+def test_widthless_sizes_vs_oracle_and_merge(name, nt, na, len_t, len_a, apart):
+    """Negative ids, no declared width.  apart = 70001: ids spread over +-1.75e8, the labels; apart = 1: ids within 5000 of
+    each other, which the library moves to start at zero instead (the table kernels as they are)."""
     tu, au = PAIRINGS[name]
     rng = np.random.default_rng(nt * 7 + na + len_t)
     width = 5000
@@ -37,7 +40,7 @@ def test_widthless_sizes_vs_oracle_and_merge(name, nt, na, len_t, len_a):
     else:
         t = Batch(np.zeros(nt + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if tu else None)
     a = Batch(*util.ragged_rows(rng, na, width, len_a, au, lo=-2500))
-    dt, da = SDRBatch.from_csr(t.off, t.ids, t.data), SDRBatch.from_csr(a.off, a.ids, a.data)       # no declared width
+    dt, da = SDRBatch.from_csr(t.off, t.ids * apart, t.data), SDRBatch.from_csr(a.off, a.ids * apart, a.data)       # no declared width
     for op in (AND, OR, XOR, RM):
         for swap in (False, True):
             want = oracle.port().size_op(op, a, t).T if swap else oracle.port().size_op(op, t, a)
@@ -135,3 +138,93 @@ def test_undeclared_width_is_derived_from_the_ids_whatever_their_size():
     # the table kernels can be asked for by name once a width is derived
     small_t, small_a = SDRBatch.from_csr(t.off, t.ids, None), SDRBatch.from_csr(a.off, a.ids, None)
     assert np.array_equal(sizes(AND, small_t, small_a, algo="bitslice"), oracle.port().size_op(AND, Batch(t.off, t.ids, None), Batch(a.off, a.ids, None)))
+
+
+ELEMS = ((AND, "ande"), (OR, "ore"), (XOR, "xore"), (RM, "rme"))
+
+
+def assert_same_elems(got, want, id_type, what):
+    off, ids, data = got
+    w_off, w_ids, w_data = want
+    assert np.array_equal(off, w_off), what
+    assert ids.dtype == id_type and np.array_equal(ids, w_ids.astype(id_type)), what
+    assert (data is None) == (w_data is None), what
+    if data is not None:
+        assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), what
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("base,id_type", [(-1700, np.int32), (-(1 << 31), np.int32), ((1 << 31) - 4000, np.int32),
+                                          (-5, np.int64), (1 << 40, np.int64), (-(1 << 50), np.int64)])
+@pytest.mark.parametrize("nt,na,len_t,len_a", [(40, 900, 40, 40), (3, 600, 200, 300), (100, 130, 64, 64)])
+def test_ids_close_together_but_far_from_zero_take_the_table_kernels(name, base, id_type, nt, na, len_t, len_a):
+    """Ids no table indexes as they are (negative, at either end of 32 bits, 64-bit ids far beyond 32 bits) but within a
+    few thousand of each other: both batches are seen through ids less the smallest one, every kernel of the path
+    applies, and the elements come back as the ids they were -- sizes, elements of all four ops in both orientations,
+    kernels by name (which would refuse ids they cannot index), visitors' positions."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(nt + na + len_t + (base % 1000))
+    width = 4000
+    t = Batch(*util.ragged_rows(rng, nt, width, len_t, tu))
+    a = Batch(*util.ragged_rows(rng, na, width, len_a, au))
+    dt = SDRBatch.from_csr(t.off, t.ids.astype(np.int64).astype(id_type) + id_type(base), t.data)
+    da = SDRBatch.from_csr(a.off, a.ids.astype(np.int64).astype(id_type) + id_type(base), a.data)
+    back = lambda r: (r[0], r[1].astype(np.int64) + base, r[2])   # noqa: E731
+    for op, ename in ELEMS:
+        want = oracle.port().size_op(op, t, a)
+        assert np.array_equal(sizes(op, dt, da), want), NAMES[op]
+        assert np.array_equal(sizes(op, dt, da, swap=True), oracle.port().size_op(op, a, t).T), NAMES[op]
+        assert_same_elems(getattr(dt, ename)(da).to_host(), back(oracle.port().elem_op(op, t, a)), id_type, ename)
+        got = getattr(dt, ename)(da, swap=True).to_host()
+        w = back(oracle.port().elem_op(op, a, t))
+        assert np.array_equal(np.diff(got[0]).reshape(t.n, a.n), np.diff(w[0]).reshape(a.n, t.n).T), ename
+        assert np.array_equal(util.pair_digests(*got).reshape(t.n, a.n), util.pair_digests(*w).reshape(a.n, t.n).T), ename
+    # kernels by name: they index tables by id, so they only run because the ids were moved
+    assert np.array_equal(sizes(AND, dt, da, algo="masktable"), oracle.port().size_op(AND, t, a))
+    assert_same_elems(dt.ore(da, algo="rank").to_host(), back(oracle.port().elem_op(OR, t, a)), id_type, "rank")
+    # the visitors report positions, which do not move
+    for which, vname in ((0, "andv"), (1, "orv")):
+        off, tp, ap = getattr(dt, vname)(da).to_host()
+        w_off, w_tp, w_ap = oracle.port().visit(which, t, a)
+        assert np.array_equal(off, w_off) and np.array_equal(tp, w_tp) and np.array_equal(ap, w_ap), vname
+    # the merges, asked for by name, take the ids as they are
+    assert_same_elems(dt.xore(da, algo="merge").to_host(), back(oracle.port().elem_op(XOR, t, a)), id_type, "merge")
+
+
+def test_ids_of_two_widths_close_together_beyond_32_bits():
+    """A 32-bit `this` whose ids end at the top of 32 bits against 64-bit rows that go on beyond it: moved together;
+    intersections and differences come back as 32-bit ids, a union has no 32-bit result and is refused."""
+    rng = np.random.default_rng(61)
+    t = Batch(*util.ragged_rows(rng, 30, 3000, 40, True))
+    a = Batch(*util.ragged_rows(rng, 500, 6000, 40, False))
+    top = (1 << 31) - 3000
+    dt = SDRBatch.from_csr(t.off, (t.ids.astype(np.int64) + top).astype(np.int32), t.data)
+    da = SDRBatch.from_csr(a.off, a.ids.astype(np.int64) + top, None)
+    assert int(a.ids.max()) + top > (1 << 31)
+    for op, ename in ((AND, "ande"), (RM, "rme")):
+        assert np.array_equal(sizes(op, dt, da), oracle.port().size_op(op, t, a)), ename
+        w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
+        assert_same_elems(getattr(dt, ename)(da).to_host(), (w_off, w_ids.astype(np.int64) + top, w_data), np.int32, ename)
+        w_off, w_ids, w_data = oracle.port().elem_op(op, a, t)
+        assert_same_elems(getattr(da, ename)(dt).to_host(), (w_off, w_ids.astype(np.int64) + top, w_data), np.int64, ename + " 64")
+    assert np.array_equal(sizes(OR, dt, da), oracle.port().size_op(OR, t, a))
+    with pytest.raises(sdr_amd.SdrbError):
+        dt.ore(da).to_host()
+    w_off, w_ids, w_data = oracle.port().elem_op(OR, a, t)
+    assert_same_elems(da.ore(dt).to_host(), (w_off, w_ids.astype(np.int64) + top, w_data), np.int64, "ore 64")
+
+
+def test_shift_of_64_bit_ids_beyond_32_bits():
+    rng = np.random.default_rng(67)
+    a = Batch(*util.ragged_rows(rng, 200, 3000, 40, True))
+    far = a.ids.astype(np.int64) + (1 << 45)
+    d = SDRBatch.from_csr(a.off, far, a.data)
+    d.shift(-1000)
+    other = SDRBatch.from_csr(a.off, far - 1000, a.data)
+    assert np.array_equal(sizes(AND, d, other), oracle.port().size_op(AND, a, a))
+    assert np.array_equal(d.equals(other).cpu().numpy().view(np.uint32), oracle.port().equal(a, a))
+    w_off, w_ids, w_data = oracle.port().elem_op(AND, a, a)
+    assert_same_elems(d.ande(other).to_host(), (w_off, w_ids.astype(np.int64) + (1 << 45) - 1000, w_data), np.int64, "shifted")
+    near_top = SDRBatch.from_csr(a.off, a.ids.astype(np.int64) + ((1 << 63) - 5000), a.data)
+    with pytest.raises(sdr_amd.SdrbError):
+        near_top.shift(3000)                      # would leave 64 bits

@@ -92,24 +92,43 @@ def main():
             out = torch.empty((nq, nd), dtype=torch.int32, device="cuda:0")
             times = {}
             # "undeclared": no width given, no negative id -- the library derives one (largest id + 1);
-            # "widthless": the same rows with every id moved down by 1000, so that there is no width to derive
-            for label, w, shift in (("declared", width, 0), ("undeclared", 0, 0), ("widthless", 0, 1000)):
-                q = SDRBatch.from_csr(q_csr[0], q_csr[1] - shift, q_csr[2], width=w)
-                d = SDRBatch.from_csr(d_csr[0], d_csr[1] - shift, d_csr[2], width=w)
+            # "moved": the same rows with every id moved down by 1000 -- no width to derive, but ids close together, which
+            #          the library moves to start at zero for the call;
+            # "widthless": ids far apart and partly negative (times 100003, less 10^9): small labels, then the table kernels
+            far = lambda x: (x.astype(np.int64) * 100003 - 1000000000).astype(np.int32)   # noqa: E731
+            ename = "ande" if sname == "ands" else "ore"
+            for label, w, f in (("declared", width, lambda x: x), ("undeclared", 0, lambda x: x), ("moved", 0, lambda x: x - 1000),
+                                ("widthless", 0, far)):
+                q = SDRBatch.from_csr(q_csr[0], f(q_csr[1]), q_csr[2], width=w)
+                d = SDRBatch.from_csr(d_csr[0], f(d_csr[1]), d_csr[2], width=w)
                 times[label], _ = timed(lambda: getattr(q, sname)(d, out=out), args.reps)
-                if shift:
+                if label == "widthless":
                     ref = out.clone()
                     times["merge"], _ = timed(lambda: getattr(q, sname)(d, out=out, algo="merge"), max(1, args.reps // 2))
                     same = bool(torch.equal(ref, out))
+                if label in ("declared", "moved") and nq <= 64 and ename == "ande":
+                    # the elements too: ids moved to zero take the table kernels, ids as they are the per-pair merge
+                    times[label + "_elems"], res = timed(lambda: getattr(q, ename)(d), max(1, args.reps // 2))
+                    if label == "moved":
+                        times["merge_elems"], res_m = timed(lambda: getattr(q, ename)(d, algo="merge"), max(1, args.reps // 4))
+                        elems_equal = bool(torch.equal(res.offsets, res_m.offsets) and torch.equal(res.ids, res_m.ids))
+                        del res_m
+                    del res
                 del q, d
             eb = 8 if unit and sname != "ors" else 4
             nbytes = (nd + nq) * (eb * active + 4) + nq * nd * 4
-            print(json.dumps({"case": "widthless", "shape": tag, "queries": nq, "rows": nd, "width": width, "active": active,
-                              "unit": unit, "op": sname, "declared_ms": round(times["declared"], 4),
-                              "undeclared_ms": round(times["undeclared"], 4), "widthless_ms": round(times["widthless"], 4), "merge_ms": round(times["merge"], 4),
-                              "speedup_over_merge": round(times["merge"] / times["widthless"], 1), "equal": same,
-                              "widthless_GBps": round(nbytes / times["widthless"] / 1e6, 1),
-                              "merge_pair_ops_per_s": round(nq * nd / (times["merge"] * 1e-3), 0)}), flush=True)
+            line = {"case": "widthless", "shape": tag, "queries": nq, "rows": nd, "width": width, "active": active,
+                    "unit": unit, "op": sname, "declared_ms": round(times["declared"], 4),
+                    "undeclared_ms": round(times["undeclared"], 4), "moved_ms": round(times["moved"], 4),
+                    "widthless_ms": round(times["widthless"], 4), "merge_ms": round(times["merge"], 4),
+                    "speedup_over_merge": round(times["merge"] / times["widthless"], 1), "equal": same,
+                    "widthless_GBps": round(nbytes / times["widthless"] / 1e6, 1),
+                    "merge_pair_ops_per_s": round(nq * nd / (times["merge"] * 1e-3), 0)}
+            if "moved_elems" in times:
+                line.update({"elem_op": ename, "declared_elems_ms": round(times["declared_elems"], 4),
+                             "moved_elems_ms": round(times["moved_elems"], 4), "merge_elems_ms": round(times["merge_elems"], 4),
+                             "elems_equal": elems_equal})
+            print(json.dumps(line), flush=True)
     if "inner" in args.cases:
         # sparse dot products (SDR::inner / diff_mul): 4096 x rows pairs at 2048/40 with float payloads,
         # and the matrix x vector shape (1 x rows)

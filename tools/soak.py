@@ -165,6 +165,21 @@ def main():
                     print("MISMATCH mixed id widths", SIZE[op], id_type, tag, flush=True)
                     return 1
                 checks += 2
+            # ids far from zero but close together (64-bit ids beyond 32 bits, 32-bit ids at the low end of their range):
+            # moved to zero for the call, every kernel open to them, elements back as the ids they were
+            for base, id_type in ((1 << 40, np.int64), (-(1 << 31) + 3, np.int32), (-(1 << 44) - 7, np.int64)):
+                mv = lambda x: (x.astype(np.int64) + base).astype(id_type)   # noqa: E731
+                tm = SDRBatch.from_csr(t.off, mv(t.ids), t.data)
+                am = SDRBatch.from_csr(a.off, mv(a.ids), a.data)
+                got = getattr(tm, SIZE[op])(am).cpu().numpy().view(np.uint32)
+                off, ids, data = getattr(tm, ELEM[op])(am).to_host()
+                ok = np.array_equal(got, oracle.port().size_op(op, t, a)) and np.array_equal(off, w_off) and ids.dtype == id_type and \
+                    np.array_equal(ids, mv(w_ids)) and \
+                    ((data is None and w_data is None) or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))
+                if not ok:
+                    print("MISMATCH moved ids", SIZE[op], base, tag, flush=True)
+                    return 1
+                checks += 2
             # ids no table can index: 32-bit ids spread over the whole signed range, 64-bit ids beyond 32 bits
             # (both keep the rows' order); sizes only depend on which ids rows share
             if len_a and len_b and width <= 4096:
