@@ -84,6 +84,7 @@ extern "C" {
                                         the per-pair merge) */
 #define SDRB_FLAG_FORCE_MASKTABLE 4096u /* size ops: fail with UNSUPPORTED unless the 64-row mask-table kernel applies */
 #define SDRB_FLAG_FORCE_BITSLICE_LONG 8192u /* size ops: fail with UNSUPPORTED unless the bit-sliced kernel for long rows / wide tables applies */
+#define SDRB_FLAG_FORCE_SEARCH 16384u /* element fill, visitors: fail with UNSUPPORTED unless the wave-per-pair binary-search kernel applies (any ids, as they are) */
 #define SDRB_FLAG_FORCE_MFMA 16u    /* all-pairs top-k: fail with UNSUPPORTED unless the matrix-core kernel applies */
 
 typedef struct sdrb_batch sdrb_batch;
@@ -161,7 +162,8 @@ int sdrb_batch_upload_device_csr(sdrb_batch* batch, uint64_t n_rows, const uint3
  * BOTH batches of a call are moved for the call: the kernels see copies of the ids less the smallest one (a pass over
  * each batch, scratch of the stream), with every table kernel open to them, and an element fill adds it back.  Results
  * depend on which ids are equal and on their order, never on their values (SDRElem.hpp:56-75).  Ids further apart are
- * given small labels for the size ops (batches without a usable width above) and merged pair by pair for the elements.
+ * given small labels for the size ops (batches without a usable width above); their elements are filled by a wave per
+ * pair with binary searches over the rows, whatever the ids are.
  */
 int sdrb_batch_create64(int device, int data_kind, sdrb_batch** out);
 int sdrb_batch_upload_csr64(sdrb_batch* batch, uint64_t n_rows, const uint64_t* row_offsets,

@@ -20,6 +20,7 @@ FLAG_FORCE_BITMAP, FLAG_FORCE_LANEMERGE, FLAG_FORCE_LANERANK = 256, 512, 1024
 FLAG_FORCE_SPARSE = 2048
 FLAG_FORCE_MASKTABLE = 4096
 FLAG_FORCE_BITSLICE_LONG = 8192
+FLAG_FORCE_SEARCH = 16384
 
 ERROR_NAMES = {
     -1: "SDRB_ERR_INVALID_ARG",

@@ -399,9 +399,11 @@ class SDRBatch:
             f |= _lib.FLAG_FORCE_MASKTABLE
         elif algo == "bitslice_long":   # id-only size ops by the bit-sliced kernel for long rows / wide tables
             f |= _lib.FLAG_FORCE_BITSLICE_LONG
+        elif algo == "search":      # element fill / visitors by the wave-per-pair binary-search kernel (ids as they are)
+            f |= _lib.FLAG_FORCE_SEARCH
         elif algo is not None:
             raise ValueError("algo must be None, 'merge', 'bitslice', 'popcount', 'rowtable', 'rank', 'bitmap', "
-                             "'lanemerge', 'lanerank', 'lanerows', 'masktable' or 'bitslice_long'")
+                             "'lanemerge', 'lanerank', 'lanerows', 'masktable', 'bitslice_long' or 'search'")
         return f
 
     def _size_op_narrow(self, op: int, other: "SDRBatch", swap: bool, out, stream, dtype):

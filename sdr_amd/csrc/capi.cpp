@@ -275,7 +275,7 @@ bool id_span(const sdrb_batch* b, int64_t* lo, int64_t* hi) {
 
 int move_ids_to_zero(const sdrb_batch*& a, const sdrb_batch*& b, unsigned flags, hipStream_t s, IdHarmony* h) {
     // (row by row, and where the caller asks for them, the merges serve: they take ids as they are)
-    if ((flags & (SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_ROWWISE | kFlagLabelled | kFlagIdsAsTheyAre)) || a->device != b->device ||
+    if ((flags & (SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_FORCE_SEARCH | SDRB_FLAG_ROWWISE | kFlagLabelled | kFlagIdsAsTheyAre)) || a->device != b->device ||
         !a->d_offsets || !b->d_offsets)
         return SDRB_OK;
     const sdrb_batch* e[2] = {a->id_bits == 64 && a->narrow ? a->narrow : a, b->id_bits == 64 && b->narrow ? b->narrow : b};
@@ -1445,6 +1445,12 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
             set_error("the rank-table fill does not apply to these batches");
             return SDRB_ERR_UNSUPPORTED;
         }
+        if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && elem_search_applicable(a, b))
+            return launch_elem_search(a, b, op, swap, out_offsets, out_ids_any, out_data, as);
+        if (flags & SDRB_FLAG_FORCE_SEARCH) {
+            set_error("the binary-search fill does not apply to these batches");
+            return SDRB_ERR_UNSUPPORTED;
+        }
         return launch_elem_fill(a, b, op, swap, out_offsets, out_ids_any, out_data, rowwise, as);
     }
     DeviceGuard guard(b->device);
@@ -1453,6 +1459,13 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
         return SDRB_ERR_HIP;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & SDRB_FLAG_FORCE_SEARCH) {
+        if (rowwise || !elem_search_applicable(a, b)) {
+            set_error("the binary-search fill needs all-pairs evaluation and rows short enough to stage in LDS");
+            return SDRB_ERR_UNSUPPORTED;
+        }
+        return launch_elem_search(a, b, op, swap, out_offsets, out_ids_any, out_data, s);
+    }
     if (flags & SDRB_FLAG_FORCE_RANK) {
         if (rowwise || !elem_rank_applicable(a, b)) {
             set_error("the rank-table fill needs all-pairs evaluation, 32-bit ids and a declared width <= 32768 that holds every id");
@@ -1484,6 +1497,9 @@ int elem_op_fill_any(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned 
             return launch_elem_unit_table(a, b, op, swap, out_offsets, out_ids, out_data, s);
         if (elem_rank_applicable(a, b)) return launch_elem_rank(a, b, op, swap, out_offsets, out_ids, out_data, s);
     }
+    // ids no table indexes (any value, 32 or 64 bits): a wave per pair, ranks by binary search
+    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && elem_search_applicable(a, b))
+        return launch_elem_search(a, b, op, swap, out_offsets, out_ids_any, out_data, s);
     return launch_elem_fill(a, b, op, swap, out_offsets, out_ids_any, out_data, rowwise, s);
 }
 }  // namespace
@@ -1620,9 +1636,15 @@ int sdrb_visit_fill(const sdrb_batch* a, const sdrb_batch* b, int which, unsigne
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     IdView va(a), vb(b);
-    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && a->id_bits == 32 && elem_rank_applicable(&va.v, &vb.v))
+    if (!(flags & (SDRB_FLAG_FORCE_MERGE | SDRB_FLAG_FORCE_SEARCH)) && !rowwise && a->id_bits == 32 && elem_rank_applicable(&va.v, &vb.v))
         return launch_elem_rank(&va.v, &vb.v, op, swap, out_offsets, reinterpret_cast<int32_t*>(this_pos),
                                 reinterpret_cast<float*>(arg_pos), s, true);
+    if (!(flags & SDRB_FLAG_FORCE_MERGE) && !rowwise && elem_search_applicable(&va.v, &vb.v))
+        return launch_elem_search(&va.v, &vb.v, op, swap, out_offsets, this_pos, reinterpret_cast<float*>(arg_pos), s, true);
+    if (flags & SDRB_FLAG_FORCE_SEARCH) {
+        set_error("the binary-search kernel does not apply to these batches");
+        return SDRB_ERR_UNSUPPORTED;
+    }
     return launch_elem_visit(&va.v, &vb.v, op, swap, out_offsets, this_pos, arg_pos, rowwise, s);
 }
 

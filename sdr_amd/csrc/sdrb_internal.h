@@ -232,6 +232,14 @@ int launch_elem_fill(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap
 int launch_elem_visit(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets,
                       uint32_t* this_pos, uint32_t* arg_pos, bool rowwise, hipStream_t stream);
 
+// elem_search.hip ------------------------------------------------------------------
+// Wave-per-pair element fill whose ranks are binary searches over the other row in LDS: ids of any value, 32 or 64
+// bits wide (both batches alike), all-pairs evaluation, rows short enough to stage.  out_ids holds ids of the batches'
+// width; visit: out_ids = positions in `this` (uint32), out_data = positions in `arg` (uint32), 0xFFFFFFFF where absent.
+bool elem_search_applicable(const sdrb_batch* a, const sdrb_batch* b);
+int launch_elem_search(const sdrb_batch* a, const sdrb_batch* b, int op, bool swap, const uint32_t* out_offsets, void* out_ids,
+                       float* out_data, hipStream_t stream, bool visit = false);
+
 // elem_bitmap.hip ------------------------------------------------------------------
 // Dense-bitset fill for id-only results (`this` side EmptyData, declared width <= 4096).
 bool elem_bitmap_applicable(const sdrb_batch* a, const sdrb_batch* b, bool swap);

@@ -228,3 +228,61 @@ def test_shift_of_64_bit_ids_beyond_32_bits():
     near_top = SDRBatch.from_csr(a.off, a.ids.astype(np.int64) + ((1 << 63) - 5000), a.data)
     with pytest.raises(sdr_amd.SdrbError):
         near_top.shift(3000)                      # would leave 64 bits
+
+
+@pytest.mark.parametrize("name", list(PAIRINGS))
+@pytest.mark.parametrize("id_type", [np.int32, np.int64])
+@pytest.mark.parametrize("nt,na,len_t,len_a", [(40, 900, 40, 40), (3, 257, 200, 300), (17, 130, 64, 65), (1, 70, 0, 33),
+                                               (5, 64, 700, 1)])
+def test_wave_per_pair_search_kernel_takes_any_ids(name, id_type, nt, na, len_t, len_a):
+    """Ids far apart and partly negative (32-bit: over +-1.7e9; 64-bit: far beyond 32 bits) have no table: the element
+    ops run one wave per pair with binary searches over the other row.  By name (`algo="search"`) and as the default
+    choice, all four ops, both orientations, ragged and empty rows, rows beyond 64 elements; against the oracle and
+    the per-pair merge."""
+    tu, au = PAIRINGS[name]
+    rng = np.random.default_rng(nt * 11 + na + len_t)
+    width = 3000
+    empty = lambda n, unit: Batch(np.zeros(n + 1, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.float32) if unit else None)   # noqa: E731
+    t = Batch(*util.ragged_rows(rng, nt, width, len_t, tu, lo=-1500)) if len_t else empty(nt, tu)
+    a = Batch(*util.ragged_rows(rng, na, width, len_a, au, lo=-1500))
+    far = (lambda x: x.astype(np.int64) * 0x100000003 - 5) if id_type == np.int64 else (lambda x: (x.astype(np.int64) * 1100003 - 7).astype(np.int32))
+    dt, da = SDRBatch.from_csr(t.off, far(t.ids), t.data), SDRBatch.from_csr(a.off, far(a.ids), a.data)
+    back = lambda r: (r[0], far(r[1]), r[2])   # noqa: E731
+    for op, ename in ELEMS:
+        want = back(oracle.port().elem_op(op, t, a))
+        assert_same_elems(getattr(dt, ename)(da, algo="search").to_host(), want, id_type, ename + " search")
+        assert_same_elems(getattr(dt, ename)(da).to_host(), want, id_type, ename + " default")
+        assert_same_elems(getattr(dt, ename)(da, algo="merge").to_host(), want, id_type, ename + " merge")
+        got = getattr(dt, ename)(da, swap=True, algo="search").to_host()
+        w = back(oracle.port().elem_op(op, a, t))
+        assert np.array_equal(np.diff(got[0]).reshape(t.n, a.n), np.diff(w[0]).reshape(a.n, t.n).T), ename
+        assert np.array_equal(util.pair_digests(*got).reshape(t.n, a.n), util.pair_digests(*w).reshape(a.n, t.n).T), ename
+    for which, vname in ((0, "andv"), (1, "orv")):
+        w_off, w_tp, w_ap = oracle.port().visit(which, t, a)
+        for algo in ("search", None):
+            off, tp, ap = getattr(dt, vname)(da, algo=algo).to_host()
+            assert np.array_equal(off, w_off) and np.array_equal(tp, w_tp) and np.array_equal(ap, w_ap), (vname, algo)
+
+
+def test_search_kernel_with_arithdata_and_rows_too_long_for_it():
+    rng = np.random.default_rng(71)
+    ta = util.arith_rows(rng, 20, 3000, 60)
+    aa = util.arith_rows(rng, 300, 3000, 60)
+    far = lambda x: (x.astype(np.int64) * 700001 - 1000000000).astype(np.int32)   # noqa: E731
+    dt = SDRBatch.from_csr(ta[0], far(ta[1]), ta[2], kind="arith")
+    da = SDRBatch.from_csr(aa[0], far(aa[1]), aa[2], kind="arith")
+    for op, ename in ((AND, "ande"), (OR, "ore"), (RM, "rme")):
+        w_off, w_ids, w_data = oracle.port().elem_op(op, Batch(*ta, arith=True), Batch(*aa, arith=True))
+        for algo in ("search", "merge", None):
+            off, ids, data = getattr(dt, ename)(da, algo=algo).to_host()
+            assert np.array_equal(off, w_off) and np.array_equal(ids, far(w_ids)), (ename, algo)
+            assert np.array_equal(data.view(np.uint32), w_data.view(np.uint32)), (ename, algo)
+    # a row that does not fit LDS: the kernel is refused by name, the default falls back to the merge
+    long_off = np.array([0, 30000], np.uint64)
+    long_ids = (np.arange(30000, dtype=np.int64) * 70001 - 1000000000).astype(np.int32)
+    one = SDRBatch.from_csr(long_off, long_ids, None)
+    with pytest.raises(sdr_amd.SdrbError) as e:
+        one.ande(one, algo="search")
+    assert e.value.code == -5
+    off, ids, data = one.ande(one).to_host()
+    assert int(off[-1]) == 30000 and np.array_equal(ids, long_ids)

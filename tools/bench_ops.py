@@ -106,12 +106,16 @@ def main():
                     ref = out.clone()
                     times["merge"], _ = timed(lambda: getattr(q, sname)(d, out=out, algo="merge"), max(1, args.reps // 2))
                     same = bool(torch.equal(ref, out))
-                if label in ("declared", "moved") and nq <= 64 and ename == "ande":
+                if label in ("declared", "moved", "widthless") and nq <= 64 and ename == "ande":
                     # the elements too: ids moved to zero take the table kernels, ids as they are the per-pair merge
                     times[label + "_elems"], res = timed(lambda: getattr(q, ename)(d), max(1, args.reps // 2))
                     if label == "moved":
                         times["merge_elems"], res_m = timed(lambda: getattr(q, ename)(d, algo="merge"), max(1, args.reps // 4))
                         elems_equal = bool(torch.equal(res.offsets, res_m.offsets) and torch.equal(res.ids, res_m.ids))
+                        del res_m
+                    if label == "widthless":    # ids far apart: a wave per pair with binary searches against the lane-per-pair merge
+                        times["merge_far_elems"], res_m = timed(lambda: getattr(q, ename)(d, algo="merge"), max(1, args.reps // 4))
+                        far_equal = bool(torch.equal(res.offsets, res_m.offsets) and torch.equal(res.ids, res_m.ids))
                         del res_m
                     del res
                 del q, d
@@ -127,7 +131,8 @@ def main():
             if "moved_elems" in times:
                 line.update({"elem_op": ename, "declared_elems_ms": round(times["declared_elems"], 4),
                              "moved_elems_ms": round(times["moved_elems"], 4), "merge_elems_ms": round(times["merge_elems"], 4),
-                             "elems_equal": elems_equal})
+                             "elems_equal": elems_equal, "widthless_elems_ms": round(times["widthless_elems"], 4),
+                             "merge_far_elems_ms": round(times["merge_far_elems"], 4), "far_elems_equal": far_equal})
             print(json.dumps(line), flush=True)
     if "inner" in args.cases:
         # sparse dot products (SDR::inner / diff_mul): 4096 x rows pairs at 2048/40 with float payloads,

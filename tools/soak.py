@@ -102,7 +102,7 @@ def main():
                             return 1
                         checks += 1
                 w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
-                for algo in ("merge", "rank", "bitmap", "lanemerge", "lanerank", "masktable"):
+                for algo in ("merge", "rank", "bitmap", "lanemerge", "lanerank", "masktable", "search"):
                     try:
                         off, ids, data = getattr(dt, ELEM[op])(da, algo=algo).to_host()
                     except SdrbError as e:
@@ -188,6 +188,13 @@ def main():
                 for name, f in (("spread", spread), ("far", far)):
                     tw = SDRBatch.from_csr(t.off, f(t.ids), t.data)
                     aw = SDRBatch.from_csr(a.off, f(a.ids), a.data)
+                    # (elements: a wave per pair, ranks by binary search)
+                    off, ids, data = getattr(tw, ELEM[op])(aw).to_host()
+                    if not (np.array_equal(off, w_off) and np.array_equal(ids, f(w_ids)) and
+                            ((data is None and w_data is None) or np.array_equal(data.view(np.uint32), w_data.view(np.uint32)))):
+                        print("MISMATCH widthless elements", name, ELEM[op], tag, flush=True)
+                        return 1
+                    checks += 1
                     for swap in (False, True):
                         got = getattr(tw, SIZE[op])(aw, swap=swap).cpu().numpy().view(np.uint32)
                         want = oracle.port().size_op(op, a, t).T if swap else oracle.port().size_op(op, t, a)
