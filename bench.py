@@ -420,9 +420,11 @@ def secondary_configs(dev) -> dict:
                                            workload=f"{name}: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData",
                                            elements=res.total)
             del res, counts
-    # ids without a usable width (every id moved below zero: nothing to declare or derive), a 64-query slab of the
-    # headline shape: the default choice (small labels, then the table kernels) beside the per-pair merge kernel it
-    # replaced, the same rows with a declared width, and with none declared but none negative (one is derived)
+    # ids without a usable width, a 64-query slab of the headline shape.  Ids far apart and partly negative (times 100003,
+    # less 10^9: nothing to declare or derive): the default choice -- small labels, then the table kernels -- beside the
+    # per-pair merge kernel it replaced; the same rows with a declared width, with none declared but none negative (one is
+    # derived), and with every id 1000 lower (close together: moved to zero for the call).  Elements of the far ids: a
+    # wave per pair with binary searches, beside the lane-per-pair merge.
     nq = 64
     q_csr = sdr_amd.synth_csr(2, 0, nq, WIDTH, ACTIVE)
     counts = torch.empty((nq, nd), dtype=torch.int32, device=dev)
@@ -432,8 +434,13 @@ def secondary_configs(dev) -> dict:
     qu, du = SDRBatch.from_csr(*q_csr), SDRBatch.from_csr(*d_csr)
     ms_undeclared, _ = _timed(lambda: qu.ands(du, out=counts))
     same = bool(torch.equal(counts, want))
-    qn = SDRBatch.from_csr(q_csr[0], q_csr[1] - 1000, None)
-    dn = SDRBatch.from_csr(d_csr[0], d_csr[1] - 1000, None)
+    qm = SDRBatch.from_csr(q_csr[0], q_csr[1] - 1000, None)
+    dm = SDRBatch.from_csr(d_csr[0], d_csr[1] - 1000, None)
+    ms_moved, _ = _timed(lambda: qm.ands(dm, out=counts))
+    same = same and bool(torch.equal(counts, want))
+    far = lambda x: (x.astype(np.int64) * 100003 - 1000000000).astype(np.int32)   # noqa: E731
+    qn = SDRBatch.from_csr(q_csr[0], far(q_csr[1]), None)
+    dn = SDRBatch.from_csr(d_csr[0], far(d_csr[1]), None)
     ms_labels, _ = _timed(lambda: qn.ands(dn, out=counts))
     same = same and bool(torch.equal(counts, want))
     ms_merge, _ = _timed(lambda: qn.ands(dn, out=counts, algo="merge"), reps=3)
@@ -442,12 +449,19 @@ def secondary_configs(dev) -> dict:
     same = same and bool(np.array_equal(
         want[:, cols].cpu().numpy().view(np.uint32),
         oracle.port().size_op(oracle.AND, oracle.Batch(*q_csr[:2], None), oracle.Batch(*_gather_rows(d_csr[0], d_csr[1], sample)[:2], None))))
+    ms_far_ande, res_far = _timed(lambda: qn.ande(dn), reps=3)
+    ms_far_ande_merge, res_merge = _timed(lambda: qn.ande(dn, algo="merge"), reps=2)
+    res_declared = q.ande(d)
+    same = same and bool(torch.equal(res_far.offsets, res_merge.offsets) and torch.equal(res_far.ids, res_merge.ids) and
+                         torch.equal(res_far.offsets, res_declared.offsets) and res_far.total == res_declared.total)
+    del res_far, res_merge, res_declared
     entry = line(ms_labels, (nd + nq) * (4 * ACTIVE + 4) + nq * nd * 4, same,
-                 workload=f"ands: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData, ids moved below zero and no width declared")
-    entry.update(declared_width_ms=ms_declared, undeclared_nonnegative_ms=ms_undeclared, merge_kernel_ms=ms_merge,
-                 merge_pair_ops_per_s=nq * nd / (ms_merge * 1e-3))
+                 workload=f"ands: {nq} x {nd} rows, width {WIDTH}/{ACTIVE}, EmptyData, ids far apart and partly negative, no width declared")
+    entry.update(declared_width_ms=ms_declared, undeclared_nonnegative_ms=ms_undeclared, ids_1000_lower_moved_to_zero_ms=ms_moved,
+                 merge_kernel_ms=ms_merge, merge_pair_ops_per_s=nq * nd / (ms_merge * 1e-3),
+                 ande_far_ids_ms=ms_far_ande, ande_far_ids_lane_merge_ms=ms_far_ande_merge)
     out["widthless_ands_q64"] = entry
-    del d, q, qu, du, qn, dn, counts, want
+    del d, q, qu, du, qn, dn, qm, dm, counts, want
     torch.cuda.empty_cache()
 
     # config 4: UnitData 16384 / 328 active, one GPU's 128 Ki rows of the 1 Mi-row database, 64 queries

@@ -221,16 +221,52 @@ def main():
                     print("MISMATCH narrow", SIZE[op], dtype, tag, flush=True)
                     return 1
                 checks += 1
-        elif extra == 2 and len_a and len_b:
-            ta = util.arith_rows(rng, na, width, len_a)
-            aa = util.arith_rows(rng, nb, width, len_b)
-            dta = SDRBatch.from_csr(*ta, width=declared, kind="arith")
-            daa = SDRBatch.from_csr(*aa, width=declared, kind="arith")
-            want = oracle.port().inner(Batch(*ta), Batch(*aa)).view(np.uint32)
-            if not np.array_equal(dta.inner(daa).cpu().numpy().view(np.uint32), want):
-                print("MISMATCH inner", tag, flush=True)
-                return 1
-            checks += 1
+        elif extra == 2:
+            from sdr_amd import SdrbError
+            if len_a and len_b:
+                ta = util.arith_rows(rng, na, width, len_a)
+                aa = util.arith_rows(rng, nb, width, len_b)
+                dta = SDRBatch.from_csr(*ta, width=declared, kind="arith")
+                daa = SDRBatch.from_csr(*aa, width=declared, kind="arith")
+                want = oracle.port().inner(Batch(*ta), Batch(*aa)).view(np.uint32)
+                if not np.array_equal(dta.inner(daa).cpu().numpy().view(np.uint32), want):
+                    print("MISMATCH inner", tag, flush=True)
+                    return 1
+                checks += 1
+            # all-pairs overlap with the fused top-k (overlap descending, then the lower row), every kernel that takes the shapes
+            if declared and len_a and len_b:
+                k = int(rng.choice([1, 5, 16]))
+                counts = oracle.port().size_op(0, Batch(t.off, t.ids, None), Batch(a.off, a.ids, None)).astype(np.int64)
+                want_c, want_r = np.zeros((na, k), np.int64), np.full((na, k), -1, np.int64)
+                for i in range(na):
+                    order = np.lexsort((np.arange(nb), -counts[i]))[:k]
+                    want_c[i, : len(order)], want_r[i, : len(order)] = counts[i][order], order
+                for algo in (None, "bitslice", "mfma"):
+                    try:
+                        got_c, got_r = dt.allpairs_topk(da, k, algo=algo)
+                    except SdrbError as e:
+                        if e.code != -5:
+                            raise
+                        continue
+                    if not (np.array_equal(got_c.cpu().numpy(), want_c) and np.array_equal(got_r.cpu().numpy(), want_r)):
+                        print("MISMATCH allpairs_topk", algo, k, tag, flush=True)
+                        return 1
+                    checks += 1
+            # the transpose: row c of the result lists the rows that hold id c, ascending, with their payloads
+            if declared and len_b:
+                tr = da.transpose()
+                wire = tr.to_wire().cpu().numpy()
+                n, nnz = tr.n_rows, tr.nnz
+                rows_of = np.repeat(np.arange(nb, dtype=np.int64), np.diff(a.off).astype(np.int64))
+                order = np.lexsort((rows_of, a.ids))
+                w_off = np.concatenate(([0], np.cumsum(np.bincount(a.ids, minlength=declared))))
+                ok = n == declared and nnz == a.ids.size and np.array_equal(wire[: n + 1].view(np.uint32), w_off) and \
+                    np.array_equal(wire[n + 1: n + 1 + nnz], rows_of[order]) and \
+                    (a.data is None or np.array_equal(wire[n + 1 + nnz:].view(np.uint32), a.data[order].view(np.uint32)))
+                if not ok:
+                    print("MISMATCH transpose", tag, flush=True)
+                    return 1
+                checks += 1
         elif extra == 3:
             # row by row (the in-place forms): the diagonal of the all-pairs results; range and point queries
             n = min(na, nb)
