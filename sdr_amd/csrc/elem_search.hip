@@ -101,7 +101,10 @@ __global__ __launch_bounds__(kBlock) void k_elem_search(
 
     for (uint64_t j = j_begin; j < j_end; ++j) {
         const uint32_t b_beg = b_off[j], lb = b_off[j + 1] - b_beg;   // <= cap_b (host)
+        // where the pairs of this row of B start, and how long their results are (the offsets hold pairs + 1 entries):
+        // a pair whose result is empty -- nearly half the intersections at SDR densities -- is skipped unsearched
         const int base_reg = lane < ni ? (int)out_off[(uint64_t)(i_begin + lane) * nb + j] : 0;
+        const int size_reg = lane < ni ? (int)(out_off[(uint64_t)(i_begin + lane) * nb + j + 1] - (uint32_t)base_reg) : 0;
         for (uint32_t k = lane; k < lb; k += 64) {
             lds_store(&b_ids_l[k], b_ids[b_beg + k]);
             if constexpr (B_UNIT) lds_store(&b_val_l[k], b_data[b_beg + k]);
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_elem_search(
         for (uint32_t ii = 0; ii < ni; ++ii) {
             const uint32_t la = (uint32_t)(__builtin_amdgcn_readlane(a_off_reg, (int)ii + 1) -
                                            __builtin_amdgcn_readlane(a_off_reg, (int)ii));
+            if (__builtin_amdgcn_readlane(size_reg, (int)ii) == 0) continue;
             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane(base_reg, (int)ii);
             const Id* a_ids_l = a_ids_all + (size_t)ii * cap_a;
             const float* a_val_l = a_val_all + (size_t)ii * cap_a;
