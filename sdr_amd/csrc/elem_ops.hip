@@ -11,6 +11,8 @@
 // is converted to the result's element type (SDRElem.hpp:29-30): an EmptyData argument
 // becomes UnitData 1.0 (UnitData.hpp:13-14), a UnitData argument loses its payload in an
 // EmptyData result (EmptyData.hpp:25-27).
+#include <type_traits>
+
 #include "sdrb_device.h"
 
 #include "sdrb_internal.h"
@@ -458,7 +460,11 @@ int launch_shift_ids(void* ids, int id_bits, uint64_t n, int64_t amount, hipStre
 
 template <typename Id>
 __global__ __launch_bounds__(256) void k_rebase_ids(const Id* __restrict__ in, int32_t* __restrict__ out, uint64_t n, Id base) {
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) out[k] = (int32_t)(in[k] - base);
+    // (unsigned arithmetic: the difference fits 31 bits, the operands' own distance from zero need not fit the id type's
+    // signed range once the other batch's smallest id is subtracted)
+    using U = std::make_unsigned_t<Id>;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256)
+        out[k] = (int32_t)(uint32_t)((U)in[k] - (U)base);
 }
 
 int launch_rebase_ids(const void* in, int id_bits, int32_t* out, uint64_t n, int64_t base, hipStream_t stream) {
@@ -474,7 +480,8 @@ int launch_rebase_ids(const void* in, int id_bits, int32_t* out, uint64_t n, int
 // the element count of a result lives on the device (its last offset): the grid is fixed and strides over it
 __global__ __launch_bounds__(256) void k_unbase_ids32(int32_t* __restrict__ ids, const uint32_t* __restrict__ n_dev, int32_t base) {
     const uint64_t n = *n_dev;
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) ids[k] += base;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256)
+        ids[k] = (int32_t)((uint32_t)ids[k] + (uint32_t)base);
 }
 __global__ __launch_bounds__(256) void k_unbase_ids64(const int32_t* __restrict__ in, int64_t* __restrict__ out,
                                                       const uint32_t* __restrict__ n_dev, long long base) {

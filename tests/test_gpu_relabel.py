@@ -191,16 +191,24 @@ def test_ids_close_together_but_far_from_zero_take_the_table_kernels(name, base,
     assert_same_elems(dt.xore(da, algo="merge").to_host(), back(oracle.port().elem_op(XOR, t, a)), id_type, "merge")
 
 
-def test_ids_of_two_widths_close_together_beyond_32_bits():
-    """A 32-bit `this` whose ids end at the top of 32 bits against 64-bit rows that go on beyond it: moved together;
-    intersections and differences come back as 32-bit ids, a union has no 32-bit result and is refused."""
+@pytest.mark.parametrize("end", ["top", "bottom"])
+def test_ids_of_two_widths_close_together_beyond_32_bits(end):
+    """A 32-bit `this` whose ids end at the top of 32 bits against 64-bit rows that go on beyond it (or start at the
+    bottom, the 64-bit rows reaching below): moved together; intersections and differences come back as 32-bit ids, a
+    union has no 32-bit result and is refused."""
     rng = np.random.default_rng(61)
-    t = Batch(*util.ragged_rows(rng, 30, 3000, 40, True))
-    a = Batch(*util.ragged_rows(rng, 500, 6000, 40, False))
-    top = (1 << 31) - 3000
+    if end == "top":
+        t = Batch(*util.ragged_rows(rng, 30, 3000, 40, True))
+        a = Batch(*util.ragged_rows(rng, 500, 6000, 40, False))
+        top = (1 << 31) - 3000
+        assert int(a.ids.max()) + top > (1 << 31)
+    else:
+        t = Batch(*util.ragged_rows(rng, 30, 3000, 40, True))
+        a = Batch(*util.ragged_rows(rng, 500, 6000, 40, False, lo=-3000))
+        top = -(1 << 31)
+        assert int(a.ids.min()) + top < -(1 << 31)
     dt = SDRBatch.from_csr(t.off, (t.ids.astype(np.int64) + top).astype(np.int32), t.data)
     da = SDRBatch.from_csr(a.off, a.ids.astype(np.int64) + top, None)
-    assert int(a.ids.max()) + top > (1 << 31)
     for op, ename in ((AND, "ande"), (RM, "rme")):
         assert np.array_equal(sizes(op, dt, da), oracle.port().size_op(op, t, a)), ename
         w_off, w_ids, w_data = oracle.port().elem_op(op, t, a)
