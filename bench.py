@@ -91,9 +91,20 @@ def main() -> None:
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    trace_on = os.environ.get("SDRB_BENCH_TRACE") == "1"
+
+    def trace(what):   # SDRB_BENCH_TRACE=1: where every rank is, on stderr
+        if trace_on:
+            print(f"[bench rank {rank}] {what}", file=sys.stderr, flush=True)
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # SDRB_BENCH_REHEARSE_ON_ONE_GPU=1: every rank uses GPU 0 and the collectives run over gloo (RCCL refuses two ranks
+    # on one device) -- a rehearsal of the N > 1 control flow on a one-GPU box; its line says so and is no measurement
+    rehearsal = os.environ.get("SDRB_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     use_dist = world > 1 or args.force_collectives
@@ -101,8 +112,12 @@ def main() -> None:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
+    trace("process group up" if use_dist else "single process")
     nq, nd = args.queries, args.rows
     engine = HipEngine(local_rank)
 
@@ -119,11 +134,19 @@ def main() -> None:
     if rank != 0:
         packed_q = None
     out = torch.empty((nq, nd), dtype=torch.int32, device=dev)
+    trace("inputs packed")
     state = {"queries": db.broadcast_packed(packed_q, plan, src=0, force_collective=args.force_collectives, recv=recv)}
+    trace("queries exchanged once")
 
     def step():
         # N > 1: one RCCL broadcast of the packed queries, adopted in place, then the kernel
         if use_dist:
+            if rehearsal:
+                # two processes that each keep several 3 ms kernels queued on ONE GPU while gloo stages the exchange
+                # through the host did not finish on the test boxes (steps 5, warm-up 2: every launch returned, the
+                # device never went idle); with the device idle at each exchange they do.  A rank has its own GPU in a
+                # real run, and RCCL orders the broadcast on the device.
+                torch.cuda.synchronize()
             state["queries"] = db.broadcast_packed(packed_q, plan, src=0, force_collective=args.force_collectives,
                                                    recv=recv, into=state["queries"])
         getattr(state["queries"], args.op)(db.shard, out=out, algo=args.algo)
@@ -136,7 +159,9 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
+    trace("warm-up enqueued")
     fence()
+    trace("warm-up done")
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -144,7 +169,9 @@ def main() -> None:
     for _ in range(args.steps):
         step()
     ev1.record()
+    trace("timed steps enqueued")
     fence()
+    trace("timed steps done")
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # device time of the K steps on the launch stream
     if use_dist:
@@ -152,6 +179,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
+    trace("times reduced")
     # ---- parity gate on the timed output (outside the timed region)
     verified = None
     if not args.no_verify and args.op == "ands":
@@ -211,6 +239,8 @@ def main() -> None:
                          "kernel_ms": kernel_ms, "algorithmic_bytes": algorithmic_bytes(nq, nd)},
             "parity_checked": verified,
         }
+        if rehearsal:
+            line["rehearsal"] = "all ranks on GPU 0, collectives over gloo: control flow only, not a measurement"
         if world == 1 and args.op == "ands" and nq > 1:
             n0 = int(q_off[1])
             line["one_query"] = one_query_regime(engine.pack_host(q_off[:2], q_ids[:n0], None, WIDTH), db.shard, nd, dev)

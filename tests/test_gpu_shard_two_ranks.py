@@ -1,0 +1,132 @@
+"""The row-sharded driver with the HIP engine on TWO ranks: two processes share the one GPU of a test box, each packs
+its half of the database through the C ABI, the exchange step and the gathers run over `gloo` on device tensors (RCCL
+refuses two ranks on one device; the collectives called are the same `broadcast` / `all_gather`).  Everything a
+multi-GPU job does per rank except the transport itself: shard ranges, broadcast and zero-copy adoption of the packed
+queries, per-shard size and element ops on the device, the all-gathered database for all-pairs, the top-k merge --
+checked against the oracle on the whole database."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import util  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+OPS = {"ands": 0, "ors": 1, "xors": 2, "rms": 3}
+NQ, WIDTH, ACTIVE = 9, 2048, 40
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _inputs(with_data, n_rows):
+    rng = np.random.default_rng(5)  # the same global database on every rank
+    d = util.ragged_rows(rng, n_rows, WIDTH, ACTIVE, with_data)
+    q = util.ragged_rows(rng, NQ, WIDTH, ACTIVE, with_data)
+    return d, q
+
+
+def _worker(rank, world, port, with_data, n_rows, results):
+    import torch
+    import torch.distributed as dist
+    from sdr_amd.shard import HipEngine, PackedQueries, ShardedDatabase, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (d_off, d_ids, d_data), (q_off, q_ids, q_data) = _inputs(with_data, n_rows)
+        engine = HipEngine(0)
+        db = ShardedDatabase.from_global_csr(d_off, d_ids, d_data, width=WIDTH, engine=engine, rank=rank, world=world)
+        assert (db.row_lo, db.row_hi) == shard_range(n_rows, rank, world)
+        packed = None
+        if rank == 0:
+            packed = (torch.from_numpy(q_off.astype(np.int64).astype(np.int32)).cuda(), torch.from_numpy(q_ids).cuda(),
+                      None if q_data is None else torch.from_numpy(q_data).cuda())
+        queries = db.broadcast_queries(packed, src=0)
+        out = {}
+        for name in OPS:
+            local = db.size_op(name, queries)
+            assert tuple(local.shape) == (NQ, db.row_hi - db.row_lo) and local.is_cuda
+            out[name] = db.gather_counts(local).cpu().numpy()
+        # the one-collective path: every rank knows the plan, only the wire tensor travels and is adopted in place
+        wire = PackedQueries.from_host_csr(q_off, q_ids, q_data, width=WIDTH, engine=engine)
+        again = db.broadcast_packed(wire if rank == 0 else None, wire.plan, src=0)
+        assert np.array_equal(db.gather_counts(db.size_op("xors", again)).cpu().numpy(), out["xors"])
+        # element ops: results stay sharded, only the totals travel
+        res, elem_lo, elem_total = db.elem_op("xore", queries)
+        results[f"xore_{rank}"] = (db.row_lo, db.row_hi, res.offsets.cpu().numpy().view(np.uint32).astype(np.int64),
+                                   res.ids.cpu().numpy(), elem_lo, elem_total)
+        # all-pairs: the shards are all-gathered into the whole database on every rank
+        whole = db.gather_database()
+        assert whole.n_rows == n_rows and whole.nnz == d_ids.size
+        ap_c, ap_r = db.allpairs_topk(4, candidates=whole)
+        results[f"allpairs_{rank}"] = (db.row_lo, ap_c.cpu().numpy(), ap_r.cpu().numpy())
+        counts, rows = db.topk(db.size_op("ands", queries), 5)
+        f_counts, f_rows = db.query_topk(queries, 5)      # the fused kernel per shard, candidates merged
+        if not with_data:
+            assert torch.equal(f_counts, counts) and torch.equal(f_rows, rows)
+        out["topk_counts"], out["topk_rows"] = f_counts.cpu().numpy(), f_rows.cpu().numpy()
+        if rank == 0:
+            results.update(out)
+        else:  # every rank must hold the same gathered result
+            results["rank1_ands"] = out["ands"]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_data,n_rows", [(False, 3001), (True, 700)])
+def test_two_ranks_with_the_hip_engine(with_data, n_rows):
+    import oracle
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), with_data, n_rows, results), nprocs=world, join=True)
+    (d_off, d_ids, d_data), (q_off, q_ids, q_data) = _inputs(with_data, n_rows)
+    d, q = oracle.Batch(d_off, d_ids, d_data), oracle.Batch(q_off, q_ids, q_data)
+    for name, op in OPS.items():
+        assert np.array_equal(results[name].view(np.uint32), oracle.port().size_op(op, q, d)), name
+    assert np.array_equal(results["rank1_ands"], results["ands"])
+    # sharded element op: every shard's CSR equals the oracle on its columns, and the element offsets tile the total
+    x_off, x_ids, _ = oracle.port().elem_op(2, q, d)
+    x_len = np.diff(x_off.astype(np.int64)).reshape(NQ, n_rows)
+    seen = 0
+    for rank in range(world):
+        lo, hi, off, ids, elem_lo, elem_total = results[f"xore_{rank}"]
+        assert elem_lo == seen and elem_total == int(x_off[-1])
+        seen += len(ids)
+        assert np.array_equal(np.diff(off).reshape(NQ, hi - lo), x_len[:, lo:hi])
+        for i in range(NQ):
+            first, last = int(x_off[i * n_rows + lo]), int(x_off[i * n_rows + hi])     # row i's elements over this shard's columns
+            k = i * (hi - lo)
+            assert np.array_equal(ids[int(off[k]):int(off[k + hi - lo])], x_ids[first:last])
+    assert seen == int(x_off[-1])
+    # all-pairs top-4 of every row over the whole database, self match excluded; top-5 per query
+    ids_only = oracle.Batch(d_off, d_ids, None)
+    self_counts = oracle.port().size_op(0, ids_only, ids_only).astype(np.int64)
+    for rank in range(world):
+        lo, got_c, got_r = results[f"allpairs_{rank}"]
+        for n in range(0, got_r.shape[0], 7):
+            i = lo + n
+            c = self_counts[i].copy()
+            c[i] = -1
+            order = np.lexsort((np.arange(n_rows), -c))[:4]
+            assert got_r[n].tolist() == order.tolist() and got_c[n].tolist() == self_counts[i][order].tolist()
+    want = oracle.port().size_op(0, oracle.Batch(q_off, q_ids, None), ids_only).astype(np.int64)
+    for i in range(NQ):
+        order = np.lexsort((np.arange(n_rows), -want[i]))[:5]
+        assert results["topk_rows"][i].tolist() == order.tolist()
+        assert results["topk_counts"][i].tolist() == want[i][order].tolist()
