@@ -25,6 +25,9 @@ static long g_checks = 0;
 
 // long ids are spread beyond 32 bits unless `small_long` keeps them as they are (ids that 32 bits would hold too)
 static bool g_small_long = false;
+// 1: ids close together but far from zero (long ids near 2^40, int ids from -1700 on): the engine moves such ids to zero
+//    for a call; 2: int ids far apart and partly negative (times 1 100 003, less 7): no table, a wave per pair searches
+static int g_id_mode = 0;
 
 template <typename SDR_t>
 std::vector<SDR_t> make_rows(std::mt19937& rng, size_t n, int width, int max_len) {
@@ -43,8 +46,12 @@ std::vector<SDR_t> make_rows(std::mt19937& rng, size_t n, int width, int max_len
             Id id = small;
             if constexpr (sizeof(Id) > 4) {
                 // ids that need 64 bits, of either sign; every third id stays small, so that rows of `int` ids can share it
-                if (!g_small_long && small % 3 == 1) id = (Id)small * 0x100000003L + 0x4000000000L;
-                if (!g_small_long && small % 3 == 2) id = -(Id)small * 0x100000003L - 0x4000000000L;
+                if (g_id_mode == 1) id = (Id)small + ((Id)1 << 40);
+                else if (!g_small_long && small % 3 == 1) id = (Id)small * 0x100000003L + 0x4000000000L;
+                else if (!g_small_long && small % 3 == 2) id = -(Id)small * 0x100000003L - 0x4000000000L;
+            } else {
+                if (g_id_mode == 1) id = (Id)(small - 1700);
+                else if (g_id_mode == 2) id = (Id)(small * 1100003 - 7 * 1100003);
             }
             ids.insert(id);
         }
@@ -620,6 +627,18 @@ int main() {
         // (long ids BEYOND 32 bits against int ids are not compared here: the reference's search hands the long id to
         // SDRElem<int>::operator<(int), SDRElem.hpp:73-75, which truncates it; the engine compares ids by value)
         g_small_long = false;
+        // ids no table indexes as they are: close together (moved to zero for the call), far apart (searched)
+        g_id_mode = 1;
+        if (run<SDR<LE>, SDR<LE>>("long ids near 2^40", rng, 512, 0)) return 1;
+        if (run<SDR<LU>, SDR<LE>>("long ids near 2^40, u x e", rng, 200, 0)) return 1;
+        if (run<SDR<E>, SDR<E>>("int ids from -1700", rng, 512, 0)) return 1;
+        if (run<SDR<U>, SDR<U>>("int ids from -1700, unit", rng, 200, 0)) return 1;
+        if (run<SDR<E>, SDR<U>>("int ids from -1700, e x u", rng, 200, 0)) return 1;
+        g_id_mode = 2;
+        if (run<SDR<E>, SDR<E>>("int ids far apart", rng, 512, 0)) return 1;
+        if (run<SDR<U>, SDR<U>>("int ids far apart, unit", rng, 200, 0)) return 1;
+        if (run<SDR<U>, SDR<E>>("int ids far apart, u x e", rng, 200, 0)) return 1;
+        g_id_mode = 0;
         if (run_few<SDR<E>>("few rows, ande", rng, 512, 40, false)) return 1;
         if (run_few<SDR<U>>("few rows, ande, unit", rng, 300, 40, false)) return 1;
         if (run_few<SDR<U>>("few rows, ande, refill", rng, 64, 40, true)) return 1;
