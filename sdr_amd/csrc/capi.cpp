@@ -923,8 +923,9 @@ int sdrb_size_op(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flag
 int sdrb_size_op_narrow(const sdrb_batch* a, const sdrb_batch* b, int op, unsigned flags, void* out, uint64_t ld_out,
                         int out_bytes, void* stream) {
     TraceRange range("sdrb_size_op_narrow");
-    narrow_pair(a, b, flags);
-    int rc = check_pair(a, b, op);
+    IdHarmony harmony;   // 64-bit ids through their narrowed copies, ids close together moved to zero
+    int rc = harmonise_ids(a, b, flags & SDRB_FLAG_SWAP, static_cast<hipStream_t>(stream), &harmony);
+    if (rc == SDRB_OK) rc = check_pair(a, b, op);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_size_op_narrow");
     if (rc != SDRB_OK) return rc;
     if (out_bytes != 1 && out_bytes != 2) {

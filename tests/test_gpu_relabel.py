@@ -179,6 +179,11 @@ def test_ids_close_together_but_far_from_zero_take_the_table_kernels(name, base,
         w = back(oracle.port().elem_op(op, a, t))
         assert np.array_equal(np.diff(got[0]).reshape(t.n, a.n), np.diff(w[0]).reshape(a.n, t.n).T), ename
         assert np.array_equal(util.pair_digests(*got).reshape(t.n, a.n), util.pair_digests(*w).reshape(a.n, t.n).T), ename
+    # counts as bytes (the bit-sliced kernel's shapes: sizes that ids alone decide, rows of at most 64 ids)
+    if (not tu) and len_a <= 64 and len_t <= 200:
+        import torch
+        got = dt.ands(da, dtype=torch.uint8).cpu().contiguous().numpy()
+        assert np.array_equal(got.astype(np.uint32), oracle.port().size_op(AND, t, a))
     # kernels by name: they index tables by id, so they only run because the ids were moved
     assert np.array_equal(sizes(AND, dt, da, algo="masktable"), oracle.port().size_op(AND, t, a))
     assert_same_elems(dt.ore(da, algo="rank").to_host(), back(oracle.port().elem_op(OR, t, a)), id_type, "rank")
