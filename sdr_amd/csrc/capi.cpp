@@ -1199,7 +1199,10 @@ int sdrb_point_query(const sdrb_batch* b, uint64_t n_ids, const int32_t* ids, in
 int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* out, uint64_t ld_out,
                void* stream) {
     TraceRange range("sdrb_inner");
-    int rc = check_pair(a, b, SDRB_OP_AND);
+    // (a dot product visits the matches in ascending id order, which ids moved to zero keep)
+    IdHarmony harmony;
+    int rc = harmonise_ids(a, b, flags & SDRB_FLAG_FORCE_MERGE, static_cast<hipStream_t>(stream), &harmony);
+    if (rc == SDRB_OK) rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_inner");
     if (rc != SDRB_OK) return rc;
     if (a->data_kind != SDRB_DATA_ARITH || b->data_kind == SDRB_DATA_UNIT) {
@@ -1223,8 +1226,9 @@ int sdrb_inner(const sdrb_batch* a, const sdrb_batch* b, unsigned flags, float* 
 int sdrb_allpairs_topk(const sdrb_batch* a, const sdrb_batch* b, uint32_t k, int64_t exclude_offset,
                        unsigned flags, uint32_t* out_counts, int32_t* out_rows, void* stream) {
     TraceRange range("sdrb_allpairs_topk");
-    narrow_pair(a, b, 0);
-    int rc = check_pair(a, b, SDRB_OP_AND);
+    IdHarmony harmony;   // overlaps depend on which ids are equal: 64-bit ids through their narrowed copies, ids close together moved to zero
+    int rc = harmonise_ids(a, b, 0, static_cast<hipStream_t>(stream), &harmony);
+    if (rc == SDRB_OK) rc = check_pair(a, b, SDRB_OP_AND);
     if (rc == SDRB_OK) rc = check_ids32(a, b, "sdrb_allpairs_topk");
     if (rc != SDRB_OK) return rc;
     if (k == 0 || !out_counts || !out_rows) {

@@ -299,3 +299,28 @@ def test_search_kernel_with_arithdata_and_rows_too_long_for_it():
     assert e.value.code == -5
     off, ids, data = one.ande(one).to_host()
     assert int(off[-1]) == 30000 and np.array_equal(ids, long_ids)
+
+
+@pytest.mark.parametrize("base,id_type", [(-1700, np.int32), (1 << 40, np.int64)])
+def test_dot_products_and_allpairs_topk_of_ids_moved_to_zero(base, id_type):
+    """`inner` visits the matches in ascending id order and the all-pairs overlap only asks which ids are equal: both are
+    served for ids close together but far from zero (64-bit ids beyond 32 bits included), with the results of the same
+    rows at their plain ids."""
+    rng = np.random.default_rng(83)
+    ta = util.arith_rows(rng, 30, 3000, 40)
+    aa = util.arith_rows(rng, 800, 3000, 40)
+    mv = lambda x: x.astype(np.int64).astype(id_type) + id_type(base)   # noqa: E731
+    if id_type == np.int32:      # (ArithData batches hold 32-bit ids)
+        dt = SDRBatch.from_csr(ta[0], mv(ta[1]), ta[2], kind="arith")
+        da = SDRBatch.from_csr(aa[0], mv(aa[1]), aa[2], kind="arith")
+        want = oracle.port().inner(Batch(*ta), Batch(*aa)).view(np.uint32)
+        assert np.array_equal(dt.inner(da).cpu().numpy().view(np.uint32), want)
+        assert np.array_equal(dt.inner(da, algo="merge").cpu().numpy().view(np.uint32), want)
+    plain_t, plain_a = SDRBatch.from_csr(ta[0], ta[1], None, width=3000), SDRBatch.from_csr(aa[0], aa[1], None, width=3000)
+    moved_t, moved_a = SDRBatch.from_csr(ta[0], mv(ta[1]), None), SDRBatch.from_csr(aa[0], mv(aa[1]), None)
+    want_c, want_r = plain_t.allpairs_topk(plain_a, 8)
+    got_c, got_r = moved_t.allpairs_topk(moved_a, 8)
+    assert np.array_equal(got_c.cpu().numpy(), want_c.cpu().numpy()) and np.array_equal(got_r.cpu().numpy(), want_r.cpu().numpy())
+    for algo in ("bitslice", "mfma"):
+        c, r = moved_t.allpairs_topk(moved_a, 8, algo=algo)
+        assert np.array_equal(c.cpu().numpy(), want_c.cpu().numpy()) and np.array_equal(r.cpu().numpy(), want_r.cpu().numpy()), algo
