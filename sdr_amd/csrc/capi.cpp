@@ -255,6 +255,7 @@ struct IdHarmony {
         bool any = false;
         for (sdrb_batch& v : at_zero) any = any || v.d_bitplanes || v.d_dense8;
         if (!any) return;
+        DeviceGuard guard(at_zero[0].device);   // (the caller's guard has gone by now)
         (void)hipStreamSynchronize(stream);
         for (sdrb_batch& v : at_zero) drop_tables(&v);
     }
